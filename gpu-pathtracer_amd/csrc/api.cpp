@@ -1,0 +1,574 @@
+// C ABI of libmipt.so (see include/mipt.h for what each entry point replaces).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mipt.h"
+#include "../host/bvh.h"
+#include "internal.h"
+#include "kernels.h"
+
+using namespace mipt;
+
+namespace mipt {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    return fail(PT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+int DeviceBuffer::reserve(size_t bytes) {
+    if (bytes <= cap) return PT_OK;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 4;
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e != hipSuccess) {
+        ptr = nullptr;
+        return hip_fail(e, "hipMalloc");
+    }
+    cap = want;
+    return PT_OK;
+}
+
+void DeviceBuffer::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+}
+
+} // namespace mipt
+
+#define PT_TRY try {
+#define PT_CATCH                                                                   \
+    }                                                                              \
+    catch (const std::bad_alloc &) { return fail(PT_ERR_NOMEM, "out of host memory"); } \
+    catch (const std::exception &e) { return fail(PT_ERR_INVALID, e.what()); }     \
+    catch (...) { return fail(PT_ERR_INVALID, "unknown error"); }
+
+#define HIP_CHECK(expr)                                                  \
+    do {                                                                 \
+        hipError_t _e = (expr);                                          \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);                \
+    } while (0)
+
+struct pt_bvh {
+    std::vector<pt_bbox> nodes;
+    uint32_t link_encoding = PT_LINKS_FLOAT_VALUE;
+};
+
+extern "C" {
+
+const char *pt_last_error(void) { return g_last_error.c_str(); }
+
+const char *pt_version(void) { return "mipt 0.1 (gfx950)"; }
+
+int pt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+/* ---------------------------------------------------------------------- */
+
+void pt_bvh_options_default(pt_bvh_options *opt) {
+    if (!opt) return;
+    opt->use_sah = 0;
+    opt->use_splits = 0;
+    opt->max_split_depth = 10;      // src/bvh/bvh_builder.cpp:28
+    opt->num_bins = 64;             // :29
+    opt->min_overlap = 0.05f;       // :30
+    opt->traversal_cost = 10.f;     // :31
+    opt->extra_node_budget = 0.5f;  // :32
+    opt->link_encoding = PT_LINKS_FLOAT_VALUE;
+    opt->num_threads = 0;
+}
+
+int pt_bvh_options_set(pt_bvh_options *opt, const char *key, const char *value) {
+    if (!opt || !key || !value) return fail(PT_ERR_INVALID, "pt_bvh_options_set: null argument");
+    PT_TRY
+    std::string err;
+    if (!set_option(*opt, key, value, err)) return fail(PT_ERR_INVALID, err);
+    return PT_OK;
+    PT_CATCH
+}
+
+int pt_mesh_leaf_bounds(const float *vtx, uint32_t n_vtx, const int32_t *idx, uint32_t n_tri,
+                        pt_bbox *out) {
+    if (!vtx || !idx || !out) return fail(PT_ERR_INVALID, "pt_mesh_leaf_bounds: null argument");
+    for (uint64_t i = 0; i < 3ull * n_tri; ++i)
+        if (idx[i] < 0 || (uint32_t)idx[i] >= n_vtx)
+            return fail(PT_ERR_INVALID, "pt_mesh_leaf_bounds: index " + std::to_string(idx[i]) +
+                                            " outside the vertex buffer");
+    PT_TRY
+    mesh_leaf_bounds(vtx, idx, n_tri, out);
+    return PT_OK;
+    PT_CATCH
+}
+
+int pt_bvh_build(const pt_bbox *leaf_bounds, uint32_t n_leaves, const pt_bvh_options *opt,
+                 pt_bvh **out) {
+    if (!leaf_bounds || !out) return fail(PT_ERR_INVALID, "pt_bvh_build: null argument");
+    *out = nullptr;
+    PT_TRY
+    pt_bvh_options o;
+    if (opt) o = *opt; else pt_bvh_options_default(&o);
+    std::vector<pt_bbox> scaled(leaf_bounds, leaf_bounds + n_leaves);
+    inflate_leaf_bounds(scaled.data(), n_leaves);
+    BvhTree tree;
+    build_tree(scaled.data(), n_leaves, o, tree);
+    auto bvh = std::make_unique<pt_bvh>();
+    bvh->link_encoding = o.link_encoding;
+    linearize_skip_links(tree, o.link_encoding, bvh->nodes);
+    *out = bvh.release();
+    return PT_OK;
+    PT_CATCH
+}
+
+uint32_t pt_bvh_node_count(const pt_bvh *bvh) { return bvh ? (uint32_t)bvh->nodes.size() : 0; }
+const pt_bbox *pt_bvh_nodes(const pt_bvh *bvh) { return bvh ? bvh->nodes.data() : nullptr; }
+uint32_t pt_bvh_link_encoding(const pt_bvh *bvh) { return bvh ? bvh->link_encoding : 0; }
+int pt_bvh_destroy(pt_bvh *bvh) {
+    delete bvh;
+    return PT_OK;
+}
+
+int pt_bvh_linearize(const pt_bbox *bounds, const int32_t *left, const int32_t *right,
+                     const int32_t *prim, uint32_t n_nodes, uint32_t link_encoding,
+                     pt_bbox *out_nodes) {
+    if (!bounds || !left || !right || !prim || !out_nodes)
+        return fail(PT_ERR_INVALID, "pt_bvh_linearize: null argument");
+    if (n_nodes == 0) return fail(PT_ERR_INVALID, "pt_bvh_linearize: empty tree");
+    PT_TRY
+    // Number the nodes in pre-order (ProcessNode, plain_bvh_translator.cpp:223-246).
+    BvhTree t;
+    t.bounds.reserve(n_nodes);
+    t.right.reserve(n_nodes);
+    t.prim.reserve(n_nodes);
+    std::vector<uint8_t> seen(n_nodes, 0);
+    struct Frame { uint32_t node; int32_t parent_slot; };
+    std::vector<Frame> stack;
+    stack.push_back({0, -1});
+    uint32_t leaves = 0;
+    while (!stack.empty()) {
+        const Frame f = stack.back();
+        stack.pop_back();
+        if (f.node >= n_nodes) return fail(PT_ERR_INVALID, "pt_bvh_linearize: child out of range");
+        if (seen[f.node]) return fail(PT_ERR_INVALID, "pt_bvh_linearize: node reached twice");
+        seen[f.node] = 1;
+        const int32_t slot = (int32_t)t.bounds.size();
+        if (f.parent_slot >= 0) t.right[(size_t)f.parent_slot] = slot;
+        pt_bbox b = bounds[f.node];
+        b.pmin[3] = b.pmax[3] = 0.f;
+        t.bounds.push_back(b);
+        if (left[f.node] < 0) {
+            t.right.push_back(-1);
+            t.prim.push_back(prim[f.node]);
+            if (prim[f.node] < 0)
+                return fail(PT_ERR_INVALID, "pt_bvh_linearize: leaf without a primitive");
+            ++leaves;
+        } else {
+            if (right[f.node] < 0)
+                return fail(PT_ERR_INVALID, "pt_bvh_linearize: internal node with one child");
+            t.right.push_back(-1);  // patched when the right child is numbered
+            t.prim.push_back(-1);
+            stack.push_back({(uint32_t)right[f.node], slot});   // visited after the left subtree
+            stack.push_back({(uint32_t)left[f.node], -1});
+        }
+    }
+    if (t.bounds.size() != n_nodes)
+        return fail(PT_ERR_INVALID, "pt_bvh_linearize: nodes not reachable from the root");
+    t.n_prims = leaves;
+    std::vector<pt_bbox> out;
+    linearize_skip_links(t, link_encoding, out);
+    std::memcpy(out_nodes, out.data(), sizeof(pt_bbox) * out.size());
+    return PT_OK;
+    PT_CATCH
+}
+
+int pt_bvh_validate(const pt_bbox *nodes, uint32_t n_nodes, uint32_t link_encoding,
+                    uint32_t n_tri) {
+    if (!nodes) return fail(PT_ERR_INVALID, "pt_bvh_validate: null argument");
+    PT_TRY
+    BvhTree t;
+    tree_from_skip_links(nodes, n_nodes, link_encoding, n_tri, t);
+    if (n_tri) {
+        if (t.n_prims != n_tri)
+            return fail(PT_ERR_INVALID, "skip-link array: " + std::to_string(t.n_prims) +
+                                            " leaves for " + std::to_string(n_tri) + " triangles");
+        std::vector<uint8_t> seen(n_tri, 0);
+        for (size_t i = 0; i < t.size(); ++i)
+            if (t.prim[i] >= 0) {
+                if (seen[(size_t)t.prim[i]])
+                    return fail(PT_ERR_INVALID, "skip-link array: triangle " +
+                                                    std::to_string(t.prim[i]) + " in two leaves");
+                seen[(size_t)t.prim[i]] = 1;
+            }
+    }
+    return PT_OK;
+    PT_CATCH
+}
+
+/* ---------------------------------------------------------------------- */
+
+int pt_context_create(int device, pt_context **out) {
+    if (!out) return fail(PT_ERR_INVALID, "pt_context_create: null argument");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        return fail(PT_ERR_DEVICE, "pt_context_create: no HIP device available (this library has "
+                                   "no CPU path)");
+    }
+    if (device < 0 || device >= n)
+        return fail(PT_ERR_INVALID, "pt_context_create: device " + std::to_string(device) +
+                                        " out of range (" + std::to_string(n) + " visible)");
+    PT_TRY
+    HIP_CHECK(hipSetDevice(device));
+    auto ctx = std::make_unique<pt_context>();
+    ctx->device = device;
+    HIP_CHECK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    HIP_CHECK(hipMalloc((void **)&ctx->counters, sizeof(DeviceTraceCounters)));
+    HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(DeviceTraceCounters), ctx->stream));
+    *out = ctx.release();
+    return PT_OK;
+    PT_CATCH
+}
+
+int pt_context_set_stream(pt_context *ctx, void *hip_stream) {
+    if (!ctx) return fail(PT_ERR_INVALID, "pt_context_set_stream: null context");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->external_stream = hip_stream != nullptr;
+    return PT_OK;
+}
+
+void *pt_context_stream(pt_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int pt_context_synchronize(pt_context *ctx) {
+    if (!ctx) return fail(PT_ERR_INVALID, "pt_context_synchronize: null context");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_context_set_kernel_timing(pt_context *ctx, int on) {
+    if (!ctx) return fail(PT_ERR_INVALID, "pt_context_set_kernel_timing: null context");
+    ctx->kernel_timing = on != 0;
+    return PT_OK;
+}
+
+int pt_context_destroy(pt_context *ctx) {
+    if (!ctx) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->release_all();
+    delete ctx;
+    return PT_OK;
+}
+
+/* ---------------------------------------------------------------------- */
+
+int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
+                    uint32_t link_encoding, const float *vtx, uint32_t n_vtx, const int32_t *idx,
+                    uint32_t n_tri, const pt_material *materials, uint32_t n_materials,
+                    const int32_t *material_ids, pt_scene **out) {
+    if (!ctx || !nodes || !vtx || !idx || !out)
+        return fail(PT_ERR_INVALID, "pt_scene_create: null argument");
+    *out = nullptr;
+    if (n_tri == 0 || n_vtx == 0) return fail(PT_ERR_INVALID, "pt_scene_create: empty mesh");
+    if ((materials == nullptr) != (material_ids == nullptr) || (materials && n_materials == 0))
+        return fail(PT_ERR_INVALID,
+                    "pt_scene_create: materials and material_ids must be given together");
+    PT_TRY
+    HIP_CHECK(hipSetDevice(ctx->device));
+    BvhTree tree;
+    tree_from_skip_links(nodes, n_nodes, link_encoding, n_tri, tree);
+    if (tree.n_prims != n_tri)
+        return fail(PT_ERR_INVALID, "pt_scene_create: " + std::to_string(tree.n_prims) +
+                                        " leaves for " + std::to_string(n_tri) + " triangles");
+    {
+        std::vector<uint8_t> seen(n_tri, 0);
+        for (size_t i = 0; i < tree.size(); ++i)
+            if (tree.prim[i] >= 0) {
+                if (seen[(size_t)tree.prim[i]])
+                    return fail(PT_ERR_INVALID, "pt_scene_create: triangle " +
+                                                    std::to_string(tree.prim[i]) + " in two leaves");
+                seen[(size_t)tree.prim[i]] = 1;
+            }
+    }
+    for (uint64_t i = 0; i < 3ull * n_tri; ++i)
+        if (idx[i] < 0 || (uint32_t)idx[i] >= n_vtx)
+            return fail(PT_ERR_INVALID, "pt_scene_create: index " + std::to_string(idx[i]) +
+                                            " outside the vertex buffer");
+    std::vector<pt_material> mats;
+    std::vector<int32_t> mids;
+    if (materials) {
+        mats.assign(materials, materials + n_materials);
+        mids.assign(material_ids, material_ids + n_tri);
+        for (uint32_t t = 0; t < n_tri; ++t)
+            if (mids[t] < 0 || (uint32_t)mids[t] >= n_materials)
+                return fail(PT_ERR_INVALID, "pt_scene_create: material id " +
+                                                std::to_string(mids[t]) + " out of range");
+    } else {
+        pt_material m{};
+        m.kd[0] = m.kd[1] = m.kd[2] = 0.5f;
+        m.roughness = 1.f;
+        mats.push_back(m);
+        mids.assign(n_tri, 0);
+    }
+    WideBvh wide;
+    build_wide_layout(tree, vtx, n_vtx, idx, n_tri, wide);
+
+    auto sc = std::make_unique<pt_scene>();
+    sc->ctx = ctx;
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes);
+        if (e != hipSuccess) return e;
+        sc->allocs.push_back(*dst);
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    void *d_nodes, *d_vtx, *d_idx, *d_wn, *d_wt, *d_mid, *d_mat;
+    hipError_t e;
+#define UP(dst, src, bytes)                                                     \
+    if ((e = upload(&dst, src, bytes)) != hipSuccess) {                         \
+        sc->release();                                                          \
+        return hip_fail(e, "pt_scene_create upload");                           \
+    }
+    UP(d_nodes, nodes, sizeof(pt_bbox) * (size_t)n_nodes);
+    UP(d_vtx, vtx, sizeof(float) * 3 * (size_t)n_vtx);
+    UP(d_idx, idx, sizeof(int32_t) * 3 * (size_t)n_tri);
+    UP(d_wn, wide.nodes.data(), sizeof(WideNode) * wide.nodes.size());
+    UP(d_wt, wide.tris.data(), sizeof(TriRecord) * wide.tris.size());
+    UP(d_mid, mids.data(), sizeof(int32_t) * mids.size());
+    UP(d_mat, mats.data(), sizeof(pt_material) * mats.size());
+#undef UP
+    DeviceScene &d = sc->dev;
+    d.nodes = (const float4 *)d_nodes;
+    d.vtx = (const float *)d_vtx;
+    d.idx = (const int32_t *)d_idx;
+    d.wnodes = (const float4 *)d_wn;
+    d.wtris = (const float4 *)d_wt;
+    d.mat_ids = (const int32_t *)d_mid;
+    d.materials = (const pt_material *)d_mat;
+    d.n_nodes = n_nodes;
+    d.n_tri = n_tri;
+    d.n_wnodes = (uint32_t)wide.nodes.size();
+    d.n_materials = (uint32_t)mats.size();
+    d.link_enc = link_encoding;
+    d.wide_depth = wide.max_depth;
+    *out = sc.release();
+    return PT_OK;
+    PT_CATCH
+}
+
+int pt_scene_destroy(pt_scene *scene) {
+    if (!scene) return PT_OK;
+    (void)hipSetDevice(scene->ctx->device);
+    (void)hipStreamSynchronize(scene->ctx->stream);
+    scene->release();
+    delete scene;
+    return PT_OK;
+}
+
+/* ---------------------------------------------------------------------- */
+
+static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_ray *rays_dev,
+                              uint64_t n, pt_hit *hits_dev, uint32_t flags, bool count,
+                              pt_trace_stats *stats) {
+    if (n > 0xFFFFFFF0ull)
+        return fail(PT_ERR_INVALID, "pt_trace_closest: more than 2^32-16 rays in one call");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const bool exact = (flags & (PT_TRACE_EXACT_ORDER | PT_TRACE_MOLLER_TRUMBORE)) != 0;
+    const bool mt = (flags & PT_TRACE_MOLLER_TRUMBORE) != 0;
+    const bool fixup = (flags & PT_TRACE_NO_TIE_FIXUP) == 0;
+    HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(DeviceTraceCounters), st));
+    if (exact) {
+        launch_trace_skiplink(st, scene->dev, rays_dev, hits_dev, n, nullptr, nullptr, mt,
+                              count ? ctx->counters : nullptr);
+    } else {
+        uint32_t *tie_list = nullptr;
+        if (fixup) {
+            int rc = ctx->tie_list.reserve(sizeof(uint32_t) * (size_t)std::max<uint64_t>(n, 1));
+            if (rc != PT_OK) return rc;
+            tie_list = (uint32_t *)ctx->tie_list.ptr;
+        }
+        launch_trace_ordered(st, scene->dev, rays_dev, hits_dev, n, tie_list, ctx->counters, count);
+        if (fixup)
+            launch_trace_skiplink(st, scene->dev, rays_dev, hits_dev, n, tie_list,
+                                  &ctx->counters->tie_count, false, nullptr);
+    }
+    HIP_CHECK(hipGetLastError());
+    if (stats) {
+        DeviceTraceCounters c;
+        HIP_CHECK(hipMemcpyAsync(&c, ctx->counters, sizeof(c), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        stats->rays = n;
+        stats->box_tests = c.box_tests;
+        stats->tri_tests = c.tri_tests;
+        stats->tie_rays = c.tie_count;
+    }
+    return PT_OK;
+}
+
+int pt_trace_closest_device(pt_context *ctx, const pt_scene *scene, const pt_ray *rays_dev,
+                            uint64_t n, pt_hit *hits_dev, uint32_t flags) {
+    if (!ctx || !scene || (n && (!rays_dev || !hits_dev)))
+        return fail(PT_ERR_INVALID, "pt_trace_closest_device: null argument");
+    if (scene->ctx != ctx) return fail(PT_ERR_INVALID, "scene belongs to another context");
+    PT_TRY
+    return trace_closest_impl(ctx, scene, rays_dev, n, hits_dev, flags, false, nullptr);
+    PT_CATCH
+}
+
+int pt_trace_closest_device_counted(pt_context *ctx, const pt_scene *scene,
+                                    const pt_ray *rays_dev, uint64_t n, pt_hit *hits_dev,
+                                    uint32_t flags, pt_trace_stats *stats) {
+    if (!ctx || !scene || !stats || (n && (!rays_dev || !hits_dev)))
+        return fail(PT_ERR_INVALID, "pt_trace_closest_device_counted: null argument");
+    if (scene->ctx != ctx) return fail(PT_ERR_INVALID, "scene belongs to another context");
+    PT_TRY
+    return trace_closest_impl(ctx, scene, rays_dev, n, hits_dev, flags, true, stats);
+    PT_CATCH
+}
+
+int pt_trace_closest(pt_context *ctx, const pt_scene *scene, const pt_ray *rays, uint64_t n,
+                     pt_hit *hits, uint32_t flags, pt_trace_stats *stats) {
+    if (!ctx || !scene || (n && (!rays || !hits)))
+        return fail(PT_ERR_INVALID, "pt_trace_closest: null argument");
+    if (scene->ctx != ctx) return fail(PT_ERR_INVALID, "scene belongs to another context");
+    PT_TRY
+    HIP_CHECK(hipSetDevice(ctx->device));
+    if (n == 0) {
+        if (stats) *stats = pt_trace_stats{};
+        return PT_OK;
+    }
+    int rc = ctx->io_rays.reserve(sizeof(pt_ray) * n);
+    if (rc != PT_OK) return rc;
+    rc = ctx->io_hits.reserve(sizeof(pt_hit) * n);
+    if (rc != PT_OK) return rc;
+    HIP_CHECK(hipMemcpyAsync(ctx->io_rays.ptr, rays, sizeof(pt_ray) * n, hipMemcpyHostToDevice,
+                             ctx->stream));
+    rc = trace_closest_impl(ctx, scene, (const pt_ray *)ctx->io_rays.ptr, n,
+                            (pt_hit *)ctx->io_hits.ptr, flags, stats != nullptr, stats);
+    if (rc != PT_OK) return rc;
+    HIP_CHECK(hipMemcpyAsync(hits, ctx->io_hits.ptr, sizeof(pt_hit) * n, hipMemcpyDeviceToHost,
+                             ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+    PT_CATCH
+}
+
+int pt_trace_any_device(pt_context *ctx, const pt_scene *scene, const pt_ray *rays_dev, uint64_t n,
+                        int32_t *occluded_dev) {
+    if (!ctx || !scene || (n && (!rays_dev || !occluded_dev)))
+        return fail(PT_ERR_INVALID, "pt_trace_any_device: null argument");
+    if (scene->ctx != ctx) return fail(PT_ERR_INVALID, "scene belongs to another context");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    launch_trace_any(ctx->stream, scene->dev, rays_dev, occluded_dev, n);
+    HIP_CHECK(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_trace_any(pt_context *ctx, const pt_scene *scene, const pt_ray *rays, uint64_t n,
+                 int32_t *occluded) {
+    if (!ctx || !scene || (n && (!rays || !occluded)))
+        return fail(PT_ERR_INVALID, "pt_trace_any: null argument");
+    if (scene->ctx != ctx) return fail(PT_ERR_INVALID, "scene belongs to another context");
+    if (n == 0) return PT_OK;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = ctx->io_rays.reserve(sizeof(pt_ray) * n);
+    if (rc != PT_OK) return rc;
+    rc = ctx->io_hits.reserve(sizeof(int32_t) * n);
+    if (rc != PT_OK) return rc;
+    HIP_CHECK(hipMemcpyAsync(ctx->io_rays.ptr, rays, sizeof(pt_ray) * n, hipMemcpyHostToDevice,
+                             ctx->stream));
+    launch_trace_any(ctx->stream, scene->dev, (const pt_ray *)ctx->io_rays.ptr,
+                     (int32_t *)ctx->io_hits.ptr, n);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(occluded, ctx->io_hits.ptr, sizeof(int32_t) * n,
+                             hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+/* ---------------------------------------------------------------------- */
+
+static int check_camera(const pt_camera *cam, uint32_t width, uint32_t height) {
+    if (!cam) return fail(PT_ERR_INVALID, "null camera");
+    if (cam->mode != PT_CAMERA_REFERENCE && cam->mode != PT_CAMERA_PINHOLE)
+        return fail(PT_ERR_INVALID, "unknown camera mode " + std::to_string(cam->mode));
+    if (width == 0 || height == 0 || (uint64_t)width * height > 0xFFFFFFF0ull)
+        return fail(PT_ERR_INVALID, "image size out of range");
+    return PT_OK;
+}
+
+int pt_raygen_device(pt_context *ctx, const pt_camera *cam, uint32_t width, uint32_t height,
+                     pt_ray *rays_dev) {
+    if (!ctx || !rays_dev) return fail(PT_ERR_INVALID, "pt_raygen_device: null argument");
+    int rc = check_camera(cam, width, height);
+    if (rc != PT_OK) return rc;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    launch_raygen(ctx->stream, *cam, width, height, rays_dev);
+    HIP_CHECK(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_raygen(pt_context *ctx, const pt_camera *cam, uint32_t width, uint32_t height,
+              pt_ray *rays) {
+    if (!ctx || !rays) return fail(PT_ERR_INVALID, "pt_raygen: null argument");
+    int rc = check_camera(cam, width, height);
+    if (rc != PT_OK) return rc;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const uint64_t n = (uint64_t)width * height;
+    rc = ctx->io_rays.reserve(sizeof(pt_ray) * n);
+    if (rc != PT_OK) return rc;
+    launch_raygen(ctx->stream, *cam, width, height, (pt_ray *)ctx->io_rays.ptr);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(rays, ctx->io_rays.ptr, sizeof(pt_ray) * n, hipMemcpyDeviceToHost,
+                             ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_depth_shade(pt_context *ctx, const pt_hit *hits, uint64_t n, float *rgba) {
+    if (!ctx || (n && (!hits || !rgba))) return fail(PT_ERR_INVALID, "pt_depth_shade: null argument");
+    if (n == 0) return PT_OK;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = ctx->io_hits.reserve(sizeof(pt_hit) * n);
+    if (rc != PT_OK) return rc;
+    rc = ctx->io_rays.reserve(sizeof(float) * 4 * n);
+    if (rc != PT_OK) return rc;
+    HIP_CHECK(hipMemcpyAsync(ctx->io_hits.ptr, hits, sizeof(pt_hit) * n, hipMemcpyHostToDevice,
+                             ctx->stream));
+    launch_depth_shade(ctx->stream, (const pt_hit *)ctx->io_hits.ptr, n, (float *)ctx->io_rays.ptr);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(rgba, ctx->io_rays.ptr, sizeof(float) * 4 * n, hipMemcpyDeviceToHost,
+                             ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+} // extern "C"

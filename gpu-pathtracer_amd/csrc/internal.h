@@ -1,0 +1,59 @@
+// Library-internal definitions of the opaque handles.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mipt.h"
+#include "kernels.h"
+
+namespace mipt {
+
+int fail(int code, const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+
+// Grow-only device allocation reused across calls.
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+};
+
+} // namespace mipt
+
+struct pt_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool external_stream = false;
+    bool kernel_timing = false;
+    mipt::DeviceTraceCounters *counters = nullptr;
+    mipt::DeviceBuffer tie_list;    // ray indices handed to the fixed-order kernel
+    mipt::DeviceBuffer io_rays;     // staging for the host-pointer entry points
+    mipt::DeviceBuffer io_hits;
+    mipt::DeviceBuffer render_ws;   // wavefront state of pt_render
+
+    void release_all() {
+        tie_list.release();
+        io_rays.release();
+        io_hits.release();
+        render_ws.release();
+        if (counters) (void)hipFree(counters);
+        counters = nullptr;
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+        own_stream = nullptr;
+    }
+};
+
+struct pt_scene {
+    pt_context *ctx = nullptr;
+    mipt::DeviceScene dev{};
+    std::vector<void *> allocs;
+    void release() {
+        for (void *p : allocs) (void)hipFree(p);
+        allocs.clear();
+    }
+};

@@ -1,0 +1,55 @@
+// Internal launch interface between the C ABI (api.cpp) and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mipt.h"
+
+namespace mipt {
+
+// Device-resident scene, passed to kernels by value.
+struct DeviceScene {
+    // The three buffers the reference shader binds (shaders/RadeonRays/bvh.glslh:103-117).
+    const float4 *nodes;   // 2 x float4 per skip-link node
+    const float *vtx;      // xyz packed
+    const int32_t *idx;    // 3 per triangle
+    // Re-laid-out copies for the ordered traversal.
+    const float4 *wnodes;  // 4 x float4 per two-child node (64 B)
+    const float4 *wtris;   // 3 x float4 per triangle record (48 B), leaf order
+    const int32_t *mat_ids;
+    const pt_material *materials;
+    uint32_t n_nodes, n_tri, n_wnodes, n_materials;
+    uint32_t link_enc;
+    uint32_t wide_depth;
+};
+
+// Device counters of a trace call (mirrors pt_trace_stats, device side).
+struct DeviceTraceCounters {
+    unsigned long long box_tests;
+    unsigned long long tri_tests;
+    unsigned int tie_count;   // entries appended to the tie list
+    unsigned int _pad;
+};
+
+// Closest hit in the reference's fixed skip-link order.  If list != nullptr the
+// kernel processes rays list[0 .. *list_count) instead of 0 .. n.
+void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
+                           uint64_t n, const uint32_t *list, const unsigned int *list_count,
+                           bool moller_trumbore, DeviceTraceCounters *counters);
+
+// Closest hit by ordered two-child traversal; rays whose result could depend on
+// the visiting order are appended to tie_list / counters->tie_count.
+void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
+                          uint64_t n, uint32_t *tie_list, DeviceTraceCounters *counters,
+                          bool count_work);
+
+void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, int32_t *occluded,
+                      uint64_t n);
+
+void launch_raygen(hipStream_t st, const pt_camera &cam, uint32_t width, uint32_t height,
+                   pt_ray *rays);
+
+void launch_depth_shade(hipStream_t st, const pt_hit *hits, uint64_t n, float *rgba);
+
+} // namespace mipt

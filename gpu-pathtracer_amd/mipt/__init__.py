@@ -1,0 +1,368 @@
+"""ctypes binding of libmipt.so -- the MI355X path-tracing core.
+
+Thin mirror of ``include/mipt.h``: numpy arrays in, numpy arrays out, every
+non-zero status raised as :class:`MiptError` with ``pt_last_error()``.  The
+shared library is built in-tree by ``gpu-pathtracer_amd/Makefile`` (see
+``__graft_entry__.build``); importing this module fails loudly if it is
+missing -- there is no Python or CPU fallback for the device entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmipt.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C {os.path.dirname(_HERE)}` "
+        "(or __graft_entry__.build())")
+
+lib = C.CDLL(LIB_PATH)
+
+# ---------------------------------------------------------------- constants
+PT_OK, PT_ERR_INVALID, PT_ERR_DEVICE, PT_ERR_UNSUPPORTED, PT_ERR_IO, PT_ERR_NOMEM = range(6)
+PT_LINKS_FLOAT_VALUE, PT_LINKS_INT_BITS = 0, 1
+PT_CAMERA_REFERENCE, PT_CAMERA_PINHOLE = 0, 1
+PT_TRACE_DEFAULT, PT_TRACE_EXACT_ORDER, PT_TRACE_MOLLER_TRUMBORE, PT_TRACE_NO_TIE_FIXUP = 0, 1, 2, 4
+PT_RENDER_DEFAULT, PT_RENDER_DEPTH_GREY, PT_RENDER_NEE = 0, 1, 2
+
+# ---------------------------------------------------------------- dtypes
+bbox_dtype = np.dtype([("pmin", np.float32, 4), ("pmax", np.float32, 4)])
+ray_dtype = np.dtype([("o", np.float32, 4), ("d", np.float32, 4)])
+hit_dtype = np.dtype([("shapeid", np.int32), ("primid", np.int32), ("padding", np.int32, 2),
+                      ("uvwt", np.float32, 4)])
+material_dtype = np.dtype([("kd", np.float32, 3), ("roughness", np.float32),
+                           ("ks", np.float32, 3), ("_pad0", np.float32),
+                           ("ke", np.float32, 3), ("_pad1", np.float32)])
+assert bbox_dtype.itemsize == 32 and ray_dtype.itemsize == 32 and hit_dtype.itemsize == 32
+assert material_dtype.itemsize == 48
+
+
+class BvhOptions(C.Structure):
+    _fields_ = [("use_sah", C.c_int32), ("use_splits", C.c_int32), ("max_split_depth", C.c_int32),
+                ("num_bins", C.c_int32), ("min_overlap", C.c_float), ("traversal_cost", C.c_float),
+                ("extra_node_budget", C.c_float), ("link_encoding", C.c_uint32),
+                ("num_threads", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("sx", C.c_float),
+                ("c0", C.c_float * 3), ("sy", C.c_float),
+                ("c1", C.c_float * 3), ("mode", C.c_uint32),
+                ("c2", C.c_float * 3), ("_pad", C.c_float)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("sample_begin", C.c_uint32),
+                ("sample_count", C.c_uint32), ("max_depth", C.c_uint32), ("seed", C.c_uint32),
+                ("rr_start_depth", C.c_uint32), ("flags", C.c_uint32), ("tile_size", C.c_uint32),
+                ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+                ("samples_per_pass", C.c_uint32), ("background", C.c_float * 3),
+                ("ray_offset", C.c_float)]
+
+
+class TraceStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("tie_rays", C.c_uint64)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("rays_primary", C.c_uint64), ("rays_bounce", C.c_uint64),
+                ("rays_shadow", C.c_uint64), ("tie_rays", C.c_uint64),
+                ("extend_launches", C.c_uint64), ("extend_ms", C.c_double)]
+
+
+class MiptError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+        self.message = message
+
+
+# ---------------------------------------------------------------- prototypes
+_vp = C.c_void_p
+_PROTOS = {
+    "pt_last_error": (C.c_char_p, []),
+    "pt_version": (C.c_char_p, []),
+    "pt_device_count": (C.c_int, []),
+    "pt_bvh_options_default": (None, [C.POINTER(BvhOptions)]),
+    "pt_bvh_options_set": (C.c_int, [C.POINTER(BvhOptions), C.c_char_p, C.c_char_p]),
+    "pt_mesh_leaf_bounds": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, _vp]),
+    "pt_bvh_build": (C.c_int, [_vp, C.c_uint32, C.POINTER(BvhOptions), C.POINTER(_vp)]),
+    "pt_bvh_node_count": (C.c_uint32, [_vp]),
+    "pt_bvh_nodes": (_vp, [_vp]),
+    "pt_bvh_link_encoding": (C.c_uint32, [_vp]),
+    "pt_bvh_destroy": (C.c_int, [_vp]),
+    "pt_bvh_linearize": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp]),
+    "pt_bvh_validate": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "pt_obj_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "pt_mesh_vertex_count": (C.c_uint32, [_vp]),
+    "pt_mesh_triangle_count": (C.c_uint32, [_vp]),
+    "pt_mesh_material_count": (C.c_uint32, [_vp]),
+    "pt_mesh_vertices": (_vp, [_vp]),
+    "pt_mesh_indices": (_vp, [_vp]),
+    "pt_mesh_material_ids": (_vp, [_vp]),
+    "pt_mesh_materials": (_vp, [_vp]),
+    "pt_mesh_normalize_unit_cube": (C.c_int, [_vp]),
+    "pt_mesh_destroy": (C.c_int, [_vp]),
+    "pt_context_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "pt_context_set_stream": (C.c_int, [_vp, _vp]),
+    "pt_context_stream": (_vp, [_vp]),
+    "pt_context_synchronize": (C.c_int, [_vp]),
+    "pt_context_set_kernel_timing": (C.c_int, [_vp, C.c_int]),
+    "pt_context_destroy": (C.c_int, [_vp]),
+    "pt_scene_create": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp,
+                                  C.c_uint32, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
+    "pt_scene_destroy": (C.c_int, [_vp]),
+    "pt_trace_closest": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32,
+                                   C.POINTER(TraceStats)]),
+    "pt_trace_closest_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32]),
+    "pt_trace_closest_device_counted": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32,
+                                                  C.POINTER(TraceStats)]),
+    "pt_trace_any": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
+    "pt_trace_any_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
+    "pt_raygen": (C.c_int, [_vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, _vp]),
+    "pt_raygen_device": (C.c_int, [_vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, _vp]),
+    "pt_depth_shade": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+}
+for _name, (_res, _args) in _PROTOS.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error() -> str:
+    return lib.pt_last_error().decode()
+
+
+def _check(rc: int) -> None:
+    if rc != PT_OK:
+        raise MiptError(rc, last_error())
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def _as(a, dtype, name) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if not a.flags.c_contiguous:
+        raise ValueError(f"{name} must be contiguous")
+    return a
+
+
+def device_count() -> int:
+    return int(lib.pt_device_count())
+
+
+# ---------------------------------------------------------------- host BVH path
+def bvh_options(**kw) -> BvhOptions:
+    """Options with the reference's string keys, e.g. ``bvh_options(**{"bvh.builder": "sah"})``."""
+    opt = BvhOptions()
+    lib.pt_bvh_options_default(C.byref(opt))
+    for k, v in kw.items():
+        _check(lib.pt_bvh_options_set(C.byref(opt), k.encode(), str(v).encode()))
+    return opt
+
+
+def mesh_leaf_bounds(vtx, idx) -> np.ndarray:
+    vtx = _as(vtx, np.float32, "vtx").reshape(-1, 3)
+    idx = _as(idx, np.int32, "idx").reshape(-1, 3)
+    out = np.empty(idx.shape[0], dtype=bbox_dtype)
+    _check(lib.pt_mesh_leaf_bounds(_ptr(vtx), vtx.shape[0], _ptr(idx), idx.shape[0], _ptr(out)))
+    return out
+
+
+def build_bvh(leaf_bounds, options: Optional[BvhOptions] = None) -> np.ndarray:
+    """``bvh::build_bvh``: leaf boxes -> skip-link node array (a copy owned by numpy)."""
+    leaf_bounds = _as(leaf_bounds, bbox_dtype, "leaf_bounds")
+    h = _vp()
+    _check(lib.pt_bvh_build(_ptr(leaf_bounds), leaf_bounds.shape[0],
+                            C.byref(options) if options is not None else None, C.byref(h)))
+    try:
+        n = lib.pt_bvh_node_count(h)
+        src = (C.c_char * (n * 32)).from_address(lib.pt_bvh_nodes(h))
+        return np.frombuffer(src, dtype=bbox_dtype).copy()
+    finally:
+        lib.pt_bvh_destroy(h)
+
+
+def linearize(bounds, left, right, prim, link_encoding=PT_LINKS_FLOAT_VALUE) -> np.ndarray:
+    bounds = _as(bounds, bbox_dtype, "bounds")
+    left = _as(left, np.int32, "left")
+    right = _as(right, np.int32, "right")
+    prim = _as(prim, np.int32, "prim")
+    out = np.empty(bounds.shape[0], dtype=bbox_dtype)
+    _check(lib.pt_bvh_linearize(_ptr(bounds), _ptr(left), _ptr(right), _ptr(prim), bounds.shape[0],
+                                link_encoding, _ptr(out)))
+    return out
+
+
+def validate_bvh(nodes, n_tri=0, link_encoding=PT_LINKS_FLOAT_VALUE) -> None:
+    nodes = _as(nodes, bbox_dtype, "nodes")
+    _check(lib.pt_bvh_validate(_ptr(nodes), nodes.shape[0], link_encoding, n_tri))
+
+
+class Mesh:
+    """Result of ``pt_obj_load`` copied into numpy arrays."""
+
+    def __init__(self, path: str, normalize: bool = False):
+        h = _vp()
+        _check(lib.pt_obj_load(os.fsencode(path), C.byref(h)))
+        try:
+            if normalize:
+                _check(lib.pt_mesh_normalize_unit_cube(h))
+            nv, nt, nm = (lib.pt_mesh_vertex_count(h), lib.pt_mesh_triangle_count(h),
+                          lib.pt_mesh_material_count(h))
+
+            def grab(ptr, nbytes, dtype):
+                return np.frombuffer((C.c_char * nbytes).from_address(ptr), dtype=dtype).copy()
+
+            self.vtx = grab(lib.pt_mesh_vertices(h), nv * 12, np.float32).reshape(-1, 3)
+            self.idx = grab(lib.pt_mesh_indices(h), nt * 12, np.int32).reshape(-1, 3)
+            self.material_ids = grab(lib.pt_mesh_material_ids(h), nt * 4, np.int32)
+            self.materials = grab(lib.pt_mesh_materials(h), nm * 48, material_dtype)
+        finally:
+            lib.pt_mesh_destroy(h)
+
+
+# ---------------------------------------------------------------- device side
+class Context:
+    def __init__(self, device: int = 0):
+        self._h = _vp()
+        _check(lib.pt_context_create(device, C.byref(self._h)))
+        self.device = device
+
+    def set_stream(self, hip_stream: Optional[int]) -> None:
+        _check(lib.pt_context_set_stream(self._h, hip_stream))
+
+    @property
+    def stream(self) -> int:
+        return lib.pt_context_stream(self._h) or 0
+
+    def synchronize(self) -> None:
+        _check(lib.pt_context_synchronize(self._h))
+
+    def set_kernel_timing(self, on: bool) -> None:
+        _check(lib.pt_context_set_kernel_timing(self._h, int(on)))
+
+    def close(self) -> None:
+        if self._h:
+            lib.pt_context_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host-buffer entry points
+    def raygen(self, cam: Camera, width: int, height: int) -> np.ndarray:
+        rays = np.empty(width * height, dtype=ray_dtype)
+        _check(lib.pt_raygen(self._h, C.byref(cam), width, height, _ptr(rays)))
+        return rays
+
+    def depth_shade(self, hits) -> np.ndarray:
+        hits = _as(hits, hit_dtype, "hits")
+        out = np.empty((hits.shape[0], 4), dtype=np.float32)
+        _check(lib.pt_depth_shade(self._h, _ptr(hits), hits.shape[0], _ptr(out)))
+        return out
+
+
+class Scene:
+    def __init__(self, ctx: Context, nodes, vtx, idx, materials=None, material_ids=None,
+                 link_encoding: int = PT_LINKS_FLOAT_VALUE):
+        self.ctx = ctx
+        nodes = _as(nodes, bbox_dtype, "nodes")
+        vtx = _as(vtx, np.float32, "vtx").reshape(-1, 3)
+        idx = _as(idx, np.int32, "idx").reshape(-1, 3)
+        mats = mids = None
+        if materials is not None:
+            mats = _as(materials, material_dtype, "materials")
+            mids = _as(material_ids, np.int32, "material_ids")
+            if mids.shape[0] != idx.shape[0]:
+                raise ValueError("material_ids must have one entry per triangle")
+        self.n_tri = idx.shape[0]
+        self._h = _vp()
+        _check(lib.pt_scene_create(ctx._h, _ptr(nodes), nodes.shape[0], link_encoding, _ptr(vtx),
+                                   vtx.shape[0], _ptr(idx), idx.shape[0],
+                                   _ptr(mats) if mats is not None else None,
+                                   mats.shape[0] if mats is not None else 0,
+                                   _ptr(mids) if mids is not None else None, C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib.pt_scene_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def trace_closest(self, rays, flags: int = PT_TRACE_DEFAULT, stats: bool = False):
+        rays = _as(rays, ray_dtype, "rays")
+        hits = np.empty(rays.shape[0], dtype=hit_dtype)
+        st = TraceStats()
+        _check(lib.pt_trace_closest(self.ctx._h, self._h, _ptr(rays), rays.shape[0], _ptr(hits),
+                                    flags, C.byref(st) if stats else None))
+        return (hits, st) if stats else hits
+
+    def trace_any(self, rays) -> np.ndarray:
+        rays = _as(rays, ray_dtype, "rays")
+        out = np.empty(rays.shape[0], dtype=np.int32)
+        _check(lib.pt_trace_any(self.ctx._h, self._h, _ptr(rays), rays.shape[0], _ptr(out)))
+        return out
+
+    # -- device-pointer entry points (pointers are plain ints, e.g. torch .data_ptr())
+    def trace_closest_device(self, rays_dev: int, n: int, hits_dev: int,
+                             flags: int = PT_TRACE_DEFAULT) -> None:
+        _check(lib.pt_trace_closest_device(self.ctx._h, self._h, rays_dev, n, hits_dev, flags))
+
+    def trace_closest_device_counted(self, rays_dev: int, n: int, hits_dev: int,
+                                     flags: int = PT_TRACE_DEFAULT) -> TraceStats:
+        st = TraceStats()
+        _check(lib.pt_trace_closest_device_counted(self.ctx._h, self._h, rays_dev, n, hits_dev,
+                                                   flags, C.byref(st)))
+        return st
+
+    def trace_any_device(self, rays_dev: int, n: int, out_dev: int) -> None:
+        _check(lib.pt_trace_any_device(self.ctx._h, self._h, rays_dev, n, out_dev))
+
+
+# ---------------------------------------------------------------- camera helpers
+def _normalize(v):
+    v = np.asarray(v, dtype=np.float64)
+    return v / np.linalg.norm(v)
+
+
+def look_at_camera(eye, target, up=(0.0, 1.0, 0.0), fovy_deg=40.0, aspect=1.0,
+                   mode=PT_CAMERA_PINHOLE) -> Camera:
+    """Camera looking from ``eye`` to ``target``.
+
+    c0, c1, c2 are right, up and back (the columns of mat3(inv_view)).  In
+    pinhole mode sx, sy are tan(fov/2); in reference mode they are the
+    inverse-projection diagonal the shader multiplies by (same numbers).
+    """
+    eye = np.asarray(eye, dtype=np.float64)
+    back = _normalize(eye - np.asarray(target, dtype=np.float64))
+    right = _normalize(np.cross(np.asarray(up, dtype=np.float64), back))
+    upv = np.cross(back, right)
+    cam = Camera()
+    t = float(np.tan(np.radians(fovy_deg) * 0.5))
+    for k in range(3):
+        cam.eye[k] = float(eye[k])
+        cam.c0[k] = float(right[k])
+        cam.c1[k] = float(upv[k])
+        cam.c2[k] = float(back[k])
+    cam.sx = t * aspect
+    cam.sy = t
+    cam.mode = mode
+    return cam

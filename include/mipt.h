@@ -1,0 +1,215 @@
+/*
+ * mipt.h -- C ABI of the MI355X path-tracing core (libmipt.so).
+ *
+ * The reference (zogi/gpu-pathtracer) has no plugin or FFI layer; its boundary
+ * between host C++ and GPU is the set of buffers and calls in
+ * src/main_granite.cpp (build_mesh_bvh :115-178, init_device_data :180-194,
+ * the "path_trace" pass callback :402-451) and src/bvh/bvh_builder.h:37.
+ * Every entry point below names the reference call it stands in for.
+ *
+ * Conventions
+ *  - Plain C types only: pointers, sizes, PODs.  No exceptions cross the ABI.
+ *  - Every function returning int returns PT_OK (0) or a PT_ERR_* code; the
+ *    message of the calling thread's last failure is pt_last_error().
+ *    (Reference behaviour: assert/abort, src/main.cpp:26-33.)
+ *  - Handles are opaque and owned by the caller until the matching *_destroy.
+ *    The library never frees or keeps caller memory; host arrays passed in are
+ *    copied before the call returns.
+ *  - A pt_context belongs to one GPU and is not re-entrant; different contexts
+ *    may be driven from different threads or processes.
+ *  - Pointers named *_dev are device pointers valid on the context's GPU and
+ *    the call is asynchronous on the context's stream; all others are host
+ *    pointers and the call returns after the result is in host memory.
+ */
+#ifndef MIPT_H
+#define MIPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "pt_config.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK               0
+#define PT_ERR_INVALID      1   /* bad argument or malformed input */
+#define PT_ERR_DEVICE       2   /* HIP runtime failure, or no GPU */
+#define PT_ERR_UNSUPPORTED  3
+#define PT_ERR_IO           4
+#define PT_ERR_NOMEM        5
+
+/* How leaf payloads and skip links are stored in pmin.w / pmax.w. */
+#define PT_LINKS_FLOAT_VALUE 0u /* float(index), -1.f: what the reference emits
+                                   (plain_bvh_translator.cpp:59,65-67,89,240); exact below 2^24 */
+#define PT_LINKS_INT_BITS    1u /* int32 bit pattern, 0xFFFFFFFF: the format documented at
+                                   src/bvh/bvh_builder.h:29-33 and left as a TODO in the translator */
+
+typedef struct pt_context pt_context;
+typedef struct pt_bvh pt_bvh;
+typedef struct pt_mesh pt_mesh;
+typedef struct pt_scene pt_scene;
+typedef struct pt_film pt_film;
+
+/* shaders/RadeonRays/bvh.glslh:29-33; RadeonRays::bbox as uploaded byte-for-byte at
+ * src/main_granite.cpp:191. */
+typedef struct pt_bbox { float pmin[4]; float pmax[4]; } pt_bbox;
+/* shaders/RadeonRays/bvh.glslh:37-43.  o[3] = maximum distance, d[3] = time (unused). */
+typedef struct pt_ray { float o[4]; float d[4]; } pt_ray;
+/* shaders/RadeonRays/bvh.glslh:94-101.  Miss: shapeid = primid = -1, uvwt = (0,0,0,tmax).
+ * Hit: shapeid = 0, primid = index of the triangle in the caller's index buffer,
+ * uvwt = (b0,b1,b2,t).  padding = (667, 0) always (:429-430). */
+typedef struct pt_hit { int32_t shapeid, primid, padding[2]; float uvwt[4]; } pt_hit;
+
+/* Builder options with the reference's keys and defaults
+ * (src/bvh/bvh_builder.cpp:18-32). */
+typedef struct pt_bvh_options {
+    int32_t use_sah;            /* "bvh.builder" == "sah"                    default 0 */
+    int32_t use_splits;         /* "bvh.sah.use_splits" > 0                  default 0 */
+    int32_t max_split_depth;    /* "bvh.sah.max_split_depth"                 default 10 */
+    int32_t num_bins;           /* "bvh.sah.num_bins"                        default 64 */
+    float   min_overlap;        /* "bvh.sah.min_overlap"                     default 0.05 */
+    float   traversal_cost;     /* "bvh.sah.traversal_cost"                  default 10 */
+    float   extra_node_budget;  /* "bvh.sah.extra_node_budget"               default 0.5 */
+    uint32_t link_encoding;     /* PT_LINKS_*                                default FLOAT_VALUE */
+    int32_t num_threads;        /* host threads for the build, 0 = all cores */
+} pt_bvh_options;
+
+/* Work counters of one trace call, summed over its rays. */
+typedef struct pt_trace_stats {
+    uint64_t rays;
+    uint64_t box_tests;         /* AABB slab tests */
+    uint64_t tri_tests;         /* ray/triangle tests */
+    uint64_t tie_rays;          /* rays re-resolved in skip-link order */
+} pt_trace_stats;
+
+/* Counters of one pt_render call. */
+typedef struct pt_render_stats {
+    uint64_t paths;             /* camera samples started */
+    uint64_t rays_primary;
+    uint64_t rays_bounce;
+    uint64_t rays_shadow;
+    uint64_t tie_rays;
+    uint64_t extend_launches;
+    double   extend_ms;         /* summed device time of the closest-hit kernels, if timing is on */
+} pt_render_stats;
+
+/* ------------------------------------------------------------------------ */
+/* Library                                                                  */
+const char *pt_last_error(void);
+const char *pt_version(void);
+/* Number of GPUs visible to the process; 0 without a GPU (never fails). */
+int pt_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* Host BVH path                                                            */
+
+void pt_bvh_options_default(pt_bvh_options *opt);
+/* RadeonRays::Options::SetValue as used at src/main_granite.cpp:175-176; keys as read at
+ * src/bvh/bvh_builder.cpp:18-24.  Numeric values are parsed from the string. */
+int pt_bvh_options_set(pt_bvh_options *opt, const char *key, const char *value);
+
+/* The per-triangle box recipe of build_mesh_bvh, src/main_granite.cpp:162-172.
+ * vtx: xyz packed (n_vtx*3 floats); idx: n_tri*3 vertex indices; out: n_tri boxes. */
+int pt_mesh_leaf_bounds(const float *vtx, uint32_t n_vtx, const int32_t *idx, uint32_t n_tri,
+                        pt_bbox *out);
+
+/* bvh::build_bvh, src/bvh/bvh_builder.h:37 (bvh_builder.cpp:50-76): inflates each leaf box
+ * by 1+1e-4 about its centre, builds a binary tree with one primitive per leaf and
+ * linearizes it into 2n-1 skip-link nodes (format: src/bvh/bvh_builder.h:26-34). */
+int pt_bvh_build(const pt_bbox *leaf_bounds, uint32_t n_leaves, const pt_bvh_options *opt,
+                 pt_bvh **out);
+uint32_t pt_bvh_node_count(const pt_bvh *bvh);
+/* vector<bbox> returned by build_bvh; valid until pt_bvh_destroy. */
+const pt_bbox *pt_bvh_nodes(const pt_bvh *bvh);
+uint32_t pt_bvh_link_encoding(const pt_bvh *bvh);
+int pt_bvh_destroy(pt_bvh *bvh);
+
+/* PlainBvhTranslator::Process, src/bvh/RadeonRays/plain_bvh_translator.cpp:39-96, for a tree
+ * given as arrays: node i is a leaf when left[i] < 0 (then prim[i] is its primitive),
+ * otherwise left[i]/right[i] are its children.  Node 0 is the root.  out_nodes: n_nodes. */
+int pt_bvh_linearize(const pt_bbox *bounds, const int32_t *left, const int32_t *right,
+                     const int32_t *prim, uint32_t n_nodes, uint32_t link_encoding,
+                     pt_bbox *out_nodes);
+
+/* Checks every structural property of a skip-link array (pre-order, left child adjacent,
+ * links, one leaf per triangle, child boxes inside parents' boxes is NOT required). */
+int pt_bvh_validate(const pt_bbox *nodes, uint32_t n_nodes, uint32_t link_encoding,
+                    uint32_t n_tri);
+
+/* ------------------------------------------------------------------------ */
+/* OBJ ingest: the fields the reference takes from tinyobj::LoadObj at
+ * src/main.cpp:860-899 (attrib.vertices, mesh.indices[].vertex_index of every shape,
+ * triangulated), plus per-face material ids and the MTL Kd/Ks/Ke/Ns entries. */
+int pt_obj_load(const char *path, pt_mesh **out);
+uint32_t pt_mesh_vertex_count(const pt_mesh *m);
+uint32_t pt_mesh_triangle_count(const pt_mesh *m);
+uint32_t pt_mesh_material_count(const pt_mesh *m);
+const float *pt_mesh_vertices(const pt_mesh *m);        /* xyz packed */
+const int32_t *pt_mesh_indices(const pt_mesh *m);       /* 3 per triangle */
+const int32_t *pt_mesh_material_ids(const pt_mesh *m);  /* 1 per triangle */
+const pt_material *pt_mesh_materials(const pt_mesh *m);
+/* "Scale model into unit cube", src/main.cpp:865-880. */
+int pt_mesh_normalize_unit_cube(pt_mesh *m);
+int pt_mesh_destroy(pt_mesh *m);
+
+/* ------------------------------------------------------------------------ */
+/* Device side                                                              */
+
+/* One context per GPU (the reference's Vulkan device, src/main_granite.cpp:311-315).
+ * Fails with PT_ERR_DEVICE when the process has no such GPU: there is no CPU fallback. */
+int pt_context_create(int device, pt_context **out);
+/* Run all work of this context on an existing HIP stream (hipStream_t) instead of the
+ * context's own; pass NULL to return to the own stream. */
+int pt_context_set_stream(pt_context *ctx, void *hip_stream);
+void *pt_context_stream(pt_context *ctx);
+int pt_context_synchronize(pt_context *ctx);
+/* When on, every closest-hit kernel launch of pt_render is bracketed by HIP events on the
+ * context's stream and summed into pt_render_stats.extend_ms. */
+int pt_context_set_kernel_timing(pt_context *ctx, int on);
+int pt_context_destroy(pt_context *ctx);
+
+/* init_device_data, src/main_granite.cpp:180-194: uploads the three storage buffers the
+ * shader binds (nodes / vertices / indices, shaders/RadeonRays/bvh.glslh:103-117) and
+ * derives the re-laid-out copies the ordered traversal reads.  materials / material_ids
+ * may be NULL (a single grey diffuse material is used). */
+int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
+                    uint32_t link_encoding, const float *vtx, uint32_t n_vtx,
+                    const int32_t *idx, uint32_t n_tri, const pt_material *materials,
+                    uint32_t n_materials, const int32_t *material_ids, pt_scene **out);
+int pt_scene_destroy(pt_scene *scene);
+
+/* IntersectSceneClosest, shaders/RadeonRays/bvh.glslh:417-456, for n rays.
+ * flags: PT_TRACE_*.  stats may be NULL. */
+int pt_trace_closest(pt_context *ctx, const pt_scene *scene, const pt_ray *rays, uint64_t n,
+                     pt_hit *hits, uint32_t flags, pt_trace_stats *stats);
+int pt_trace_closest_device(pt_context *ctx, const pt_scene *scene, const pt_ray *rays_dev,
+                            uint64_t n, pt_hit *hits_dev, uint32_t flags);
+/* As pt_trace_closest_device, also counting slab and triangle tests (slower; for
+ * measurement).  stats is a host pointer and the call synchronizes. */
+int pt_trace_closest_device_counted(pt_context *ctx, const pt_scene *scene,
+                                    const pt_ray *rays_dev, uint64_t n, pt_hit *hits_dev,
+                                    uint32_t flags, pt_trace_stats *stats);
+
+/* IntersectSceneAny, shaders/RadeonRays/bvh.glslh:378-414: occluded[i] = 1 or 0. */
+int pt_trace_any(pt_context *ctx, const pt_scene *scene, const pt_ray *rays, uint64_t n,
+                 int32_t *occluded);
+int pt_trace_any_device(pt_context *ctx, const pt_scene *scene, const pt_ray *rays_dev,
+                        uint64_t n, int32_t *occluded_dev);
+
+/* Camera rays for every pixel of a width x height image, row-major from the top-left
+ * pixel: shaders/depth.frag:47-83 with the pixel centre mapping of shaders/quad.vert:6,14
+ * (PT_CAMERA_REFERENCE), or a plain pinhole (PT_CAMERA_PINHOLE). */
+int pt_raygen(pt_context *ctx, const pt_camera *cam, uint32_t width, uint32_t height,
+              pt_ray *rays);
+int pt_raygen_device(pt_context *ctx, const pt_camera *cam, uint32_t width, uint32_t height,
+                     pt_ray *rays_dev);
+
+/* The colour the reference writes per pixel, shaders/depth.frag:90-107. rgba: n*4. */
+int pt_depth_shade(pt_context *ctx, const pt_hit *hits, uint64_t n, float *rgba);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

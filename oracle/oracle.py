@@ -1,0 +1,168 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+the cpu_baseline leg of bench.py as the checker / host-core baseline.  The
+product library (libmipt.so) never links or calls it.  Parity status and the
+floating-point contract are stated in pt_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+bbox_dtype = np.dtype([("pmin", np.float32, 4), ("pmax", np.float32, 4)])
+ray_dtype = np.dtype([("o", np.float32, 4), ("d", np.float32, 4)])
+isect_dtype = np.dtype([("shapeid", np.int32), ("primid", np.int32), ("padding", np.int32, 2),
+                        ("uvwt", np.float32, 4)])
+
+
+class Camera(C.Structure):
+    _fields_ = [("ip00", C.c_float), ("ip11", C.c_float),
+                ("inv_view_c0", C.c_float * 3), ("inv_view_c1", C.c_float * 3),
+                ("inv_view_c2", C.c_float * 3), ("camera_position", C.c_float * 3)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("box_tests", C.c_uint64), ("tri_tests", C.c_uint64)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc if the shared object is missing or stale."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(LIB_PATH) or
+             any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        sig = {
+            "o_closest_batch": (None, [vp, vp, vp, vp, C.c_uint64, vp, C.POINTER(Counters), C.c_int]),
+            "o_closest_mt_batch": (None, [vp, vp, vp, vp, C.c_uint64, vp, C.c_int]),
+            "o_any_batch": (None, [vp, vp, vp, vp, C.c_uint64, vp, C.c_int]),
+            "o_brute_closest_batch": (None, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, C.c_int]),
+            "o_raygen_reference_image": (None, [C.POINTER(Camera), C.c_uint32, C.c_uint32, vp]),
+            "o_depth_shade_batch": (None, [vp, C.c_uint64, vp]),
+            "o_mesh_leaf_bounds": (None, [vp, vp, C.c_uint32, vp]),
+            "o_inflate_leaf_bounds": (None, [vp, C.c_uint32]),
+            "o_build_bvh": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_int, C.c_float, vp]),
+            "o_linearize_arrays": (C.c_int, [vp, vp, vp, vp, C.c_int32, vp]),
+            "o_intersect_triangle_watertight": (C.c_int, [vp, vp, vp, vp, vp]),
+            "o_intersect_triangle_mt": (C.c_int, [vp, vp, vp, vp, vp]),
+            "o_precompute_ray": (None, [vp, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def mesh_leaf_bounds(vtx, idx) -> np.ndarray:
+    vtx, idx = _c(vtx, np.float32), _c(idx, np.int32)
+    out = np.zeros(idx.size // 3, dtype=bbox_dtype)
+    lib().o_mesh_leaf_bounds(vtx.ctypes.data, idx.ctypes.data, idx.size // 3, out.ctypes.data)
+    return out
+
+
+def inflate(boxes) -> np.ndarray:
+    b = _c(boxes, bbox_dtype).copy()
+    lib().o_inflate_leaf_bounds(b.ctypes.data, b.shape[0])
+    return b
+
+
+def build_bvh(leaf_bounds, use_sah=True, num_bins=64, traversal_cost=10.0) -> np.ndarray:
+    lb = _c(leaf_bounds, bbox_dtype)
+    out = np.zeros(2 * lb.shape[0] - 1, dtype=bbox_dtype)
+    rc = lib().o_build_bvh(lb.ctypes.data, lb.shape[0], int(use_sah), num_bins, traversal_cost,
+                           out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"o_build_bvh failed: {rc}")
+    return out
+
+
+def linearize(bounds, left, right, prim) -> np.ndarray:
+    bounds = _c(bounds, bbox_dtype)
+    left, right, prim = _c(left, np.int32), _c(right, np.int32), _c(prim, np.int32)
+    out = np.zeros(bounds.shape[0], dtype=bbox_dtype)
+    rc = lib().o_linearize_arrays(bounds.ctypes.data, left.ctypes.data, right.ctypes.data,
+                                  prim.ctypes.data, bounds.shape[0], out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"o_linearize_arrays failed: {rc}")
+    return out
+
+
+def closest(nodes, vtx, idx, rays, nthreads=1, counters=False, moller_trumbore=False):
+    nodes, vtx, idx, rays = (_c(nodes, bbox_dtype), _c(vtx, np.float32), _c(idx, np.int32),
+                             _c(rays, ray_dtype))
+    out = np.zeros(rays.shape[0], dtype=isect_dtype)
+    if moller_trumbore:
+        lib().o_closest_mt_batch(nodes.ctypes.data, vtx.ctypes.data, idx.ctypes.data,
+                                 rays.ctypes.data, rays.shape[0], out.ctypes.data, nthreads)
+        return out
+    cnt = Counters()
+    lib().o_closest_batch(nodes.ctypes.data, vtx.ctypes.data, idx.ctypes.data, rays.ctypes.data,
+                          rays.shape[0], out.ctypes.data, C.byref(cnt), nthreads)
+    return (out, cnt) if counters else out
+
+
+def any_hit(nodes, vtx, idx, rays, nthreads=1) -> np.ndarray:
+    nodes, vtx, idx, rays = (_c(nodes, bbox_dtype), _c(vtx, np.float32), _c(idx, np.int32),
+                             _c(rays, ray_dtype))
+    out = np.zeros(rays.shape[0], dtype=np.int32)
+    lib().o_any_batch(nodes.ctypes.data, vtx.ctypes.data, idx.ctypes.data, rays.ctypes.data,
+                      rays.shape[0], out.ctypes.data, nthreads)
+    return out
+
+
+def brute_closest(vtx, idx, rays, nthreads=1) -> np.ndarray:
+    vtx, idx, rays = _c(vtx, np.float32), _c(idx, np.int32), _c(rays, ray_dtype)
+    out = np.zeros(rays.shape[0], dtype=isect_dtype)
+    lib().o_brute_closest_batch(vtx.ctypes.data, idx.ctypes.data, idx.size // 3, rays.ctypes.data,
+                                rays.shape[0], out.ctypes.data, nthreads)
+    return out
+
+
+def raygen_reference(cam: Camera, width: int, height: int) -> np.ndarray:
+    out = np.zeros(width * height, dtype=ray_dtype)
+    lib().o_raygen_reference_image(C.byref(cam), width, height, out.ctypes.data)
+    return out
+
+
+def depth_shade(isects) -> np.ndarray:
+    isects = _c(isects, isect_dtype)
+    out = np.zeros((isects.shape[0], 4), dtype=np.float32)
+    lib().o_depth_shade_batch(isects.ctypes.data, isects.shape[0], out.ctypes.data)
+    return out
+
+
+def camera_from(eye, c0, c1, c2, sx, sy) -> Camera:
+    cam = Camera()
+    cam.ip00, cam.ip11 = sx, sy
+    for k in range(3):
+        cam.inv_view_c0[k] = c0[k]
+        cam.inv_view_c1[k] = c1[k]
+        cam.inv_view_c2[k] = c2[k]
+        cam.camera_position[k] = eye[k]
+    return cam

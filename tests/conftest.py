@@ -1,0 +1,64 @@
+"""Shared test plumbing: import paths, the `gpu` marker, common fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(REPO, "gpu-pathtracer_amd"), REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def mipt():
+    import mipt as m
+    return m
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.build()
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def scenes():
+    from mipt import scenes as s
+    return s
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(mipt):
+    if mipt.device_count() == 0:
+        pytest.fail("test marked gpu but no HIP device is visible")
+    ctx = mipt.Context(0)
+    yield ctx
+    ctx.close()
+
+
+def random_rays(n, seed, extent=14.0, tmax=1e30, dtype=None):
+    """Origins uniform in a cube, directions uniform on the sphere."""
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, dtype=dtype)
+    rays["o"][:, :3] = rng.uniform(-extent, extent, size=(n, 3)).astype(np.float32)
+    rays["o"][:, 3] = tmax
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays["d"][:, :3] = d.astype(np.float32)
+    return rays
+
+
+def same_hits(a, b):
+    """Bit-exact comparison of two hit arrays; returns indices that differ."""
+    bad = (a["shapeid"] != b["shapeid"]) | (a["primid"] != b["primid"])
+    bad |= (a["padding"] != b["padding"]).any(axis=1)
+    bad |= (a["uvwt"].view(np.uint32) != b["uvwt"].view(np.uint32)).any(axis=1)
+    return np.nonzero(bad)[0]

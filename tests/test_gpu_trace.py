@@ -1,0 +1,241 @@
+"""Parity of the HIP traversal kernels with the CPU oracle, through the C ABI.
+
+Bar: bit-exact pt_hit records (shapeid, primid, padding, and the raw bits of b0,b1,b2,t)
+against IntersectSceneClosest restated in oracle/pt_oracle.c, on the same nodes and rays.
+"""
+import numpy as np
+import pytest
+
+from conftest import random_rays, same_hits
+from test_oracle import cornell_rays, UNIT_TRI
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(mipt, vtx, idx, builder="sah", **opts):
+    lb = mipt.mesh_leaf_bounds(vtx, idx)
+    return mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": builder, **opts}))
+
+
+def _check_all_modes(mipt, oracle, ctx, nodes, vtx, idx, rays, expect_ties=None):
+    want = oracle.closest(nodes, vtx, idx, rays, nthreads=8)
+    sc = mipt.Scene(ctx, nodes, vtx, idx)
+    try:
+        exact = sc.trace_closest(rays, mipt.PT_TRACE_EXACT_ORDER)
+        assert len(same_hits(exact, want)) == 0, "fixed-order kernel differs from the oracle"
+        got, st = sc.trace_closest(rays, mipt.PT_TRACE_DEFAULT, stats=True)
+        bad = same_hits(got, want)
+        assert len(bad) == 0, (f"ordered kernel differs from the oracle on {len(bad)} of "
+                               f"{len(rays)} rays, first {bad[:5]}")
+        assert st.rays == len(rays)
+        if expect_ties is not None:
+            assert expect_ties(st.tie_rays), f"tie_rays = {st.tie_rays}"
+        return got, st
+    finally:
+        sc.close()
+
+
+def test_unit_triangle_and_conventions(mipt, oracle, gpu_ctx):
+    idx = np.array([[0, 1, 2]], dtype=np.int32)
+    nodes = _build(mipt, UNIT_TRI, idx)
+    rays = np.zeros(4, dtype=mipt.ray_dtype)
+    rays["o"] = [(0, 0, 5, 1e30), (2, 2, 5, 1000.0), (0, 0, 5, 4.999), (0, 0, -5, 1e30)]
+    rays["d"] = [(0, 0, -1, 0), (0, 0, -1, 0), (0, 0, -1, 0), (0, 0, 1, 0)]
+    got, _ = _check_all_modes(mipt, oracle, gpu_ctx, nodes, UNIT_TRI, idx, rays)
+    np.testing.assert_array_equal(got["uvwt"][0], np.float32([0.25, 0.5, 0.25, 5.0]))
+    assert tuple(got["primid"]) == (0, -1, -1, 0) and tuple(got["shapeid"]) == (0, -1, -1, 0)
+    assert (got["padding"] == [667, 0]).all()                      # bvh.glslh:429-430
+    np.testing.assert_array_equal(got["uvwt"][1], np.float32([0, 0, 0, 1000.0]))
+
+
+def test_fallback_quad(mipt, oracle, scenes, gpu_ctx):
+    vtx, idx, _, _ = scenes.fallback_quad()                        # src/main.cpp:918-921
+    nodes = _build(mipt, vtx, idx)
+    rays = random_rays(20000, 1, extent=3.0, dtype=mipt.ray_dtype)
+    got, _ = _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays)
+    assert set(np.unique(got["primid"])) == {-1, 0, 1}
+
+
+@pytest.mark.parametrize("builder", ["sah", "median"])
+@pytest.mark.parametrize("n_tri,seed", [(1, 0), (2, 1), (7, 2), (1000, 3), (50000, 4)])
+def test_random_soup(mipt, oracle, scenes, gpu_ctx, n_tri, seed, builder):
+    vtx, idx, _, _ = scenes.random_soup(n_tri, seed=seed)
+    nodes = _build(mipt, vtx, idx, builder)
+    rays = random_rays(100000, seed + 50, dtype=mipt.ray_dtype)
+    got, st = _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays)
+    if n_tri >= 1000:
+        assert (got["primid"] >= 0).mean() > 0.2
+        # random geometry: near ties are rare
+        assert st.tie_rays < 50
+
+
+def test_cornell_primary_rays_256(mipt, oracle, scenes, gpu_ctx):
+    """Baseline config #1 on the GPU: Cornell box, 256x256 pixel-centre primary rays, hit ids
+    bit-exact against the oracle, shared-edge ties included (they are re-resolved in the
+    reference's order; the count is reported)."""
+    vtx, idx, _, _ = scenes.cornell_box()
+    nodes = _build(mipt, vtx, idx)
+    rays = cornell_rays(256, 256).astype(mipt.ray_dtype)
+    got, st = _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays)
+    print(f"cornell 256x256: {st.tie_rays} rays re-resolved in skip-link order")
+    assert (got["primid"] >= 0).mean() > 0.9
+
+
+def test_ties_are_resolved_in_reference_order(mipt, oracle, gpu_ctx):
+    """Coplanar duplicates and shared edges: every ray has several candidates at (nearly)
+    the same distance; the answer must still be the reference's (last accepted in skip-link
+    order), and the tie path must actually have run."""
+    quad = np.array([[0, 0, 0], [2, 0, 0], [2, 2, 0], [0, 2, 0]], dtype=np.float32)
+    vtx = np.concatenate([quad, quad, quad + np.float32([0, 0, 1e-7])])
+    idx = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7], [8, 9, 10], [8, 10, 11]], np.int32)
+    for builder in ("sah", "median"):
+        nodes = _build(mipt, vtx, idx, builder)
+        n = 64
+        g = (np.arange(n) + 0.5) / n * 2
+        xx, yy = np.meshgrid(g, g)
+        rays = np.zeros(n * n + n, dtype=mipt.ray_dtype)
+        rays["o"][: n * n, 0] = xx.ravel()
+        rays["o"][: n * n, 1] = yy.ravel()
+        rays["o"][n * n:, 0] = g          # exactly on the shared diagonal
+        rays["o"][n * n:, 1] = g
+        rays["o"][:, 2] = 4
+        rays["o"][:, 3] = 1e30
+        rays["d"][:, 2] = -1
+        _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays,
+                         expect_ties=lambda t: t == n * n + n)
+
+
+def test_axis_aligned_rays_and_flat_boxes(mipt, oracle, scenes, gpu_ctx):
+    """Directions with zero components (1/d = inf, 0*inf = NaN in the slab test) against
+    axis-aligned geometry with zero-thickness boxes."""
+    vtx, idx, _, _ = scenes.cornell_box()
+    nodes = _build(mipt, vtx, idx)
+    rng = np.random.default_rng(3)
+    n = 30000
+    rays = np.zeros(n, dtype=mipt.ray_dtype)
+    rays["o"][:, :3] = rng.uniform(1, 548, size=(n, 3)).astype(np.float32)
+    rays["o"][:, 3] = 1e30
+    axis = rng.integers(0, 3, n)
+    sign = rng.choice([-1.0, 1.0], n)
+    rays["d"][np.arange(n), axis] = sign
+    # a third of them start exactly on a wall plane
+    rays["o"][: n // 3, 0] = 0.0
+    _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays)
+
+
+def test_reference_raygen_and_depth_shade(mipt, oracle, scenes, gpu_ctx):
+    """pt_raygen (depth.frag:47-83) and pt_depth_shade (:90-107) bit-exact, then the whole
+    reference frame: raygen -> closest hit -> grey."""
+    cam = mipt.look_at_camera((0.0, 0.0, -10.0), (0, 0, 0), fovy_deg=60.0, aspect=4 / 3,
+                              mode=mipt.PT_CAMERA_REFERENCE)     # main_granite.cpp:306-308
+    W, H = 160, 120
+    rays = gpu_ctx.raygen(cam, W, H)
+    ocam = oracle.camera_from(tuple(cam.eye), tuple(cam.c0), tuple(cam.c1), tuple(cam.c2),
+                              cam.sx, cam.sy)
+    want = oracle.raygen_reference(ocam, W, H)
+    np.testing.assert_array_equal(rays.view(np.uint32), want.view(np.uint32))
+    assert rays["o"][0, 3] == np.float32(20000.0)                # tmax after the vec4 divide
+    # scene scaled so the reference's x20 origin sees it
+    vtx, idx, _, _ = scenes.random_soup(3000, seed=8, extent=60.0, size=12.0)
+    vtx = vtx + np.float32([0, 40, 0])
+    nodes = _build(mipt, vtx, idx)
+    got, _ = _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays)
+    assert (got["primid"] >= 0).mean() > 0.05
+    rgba = gpu_ctx.depth_shade(got)
+    np.testing.assert_array_equal(rgba.view(np.uint32), oracle.depth_shade(got).view(np.uint32))
+
+
+def test_moller_trumbore_mode_and_any_hit(mipt, oracle, scenes, gpu_ctx):
+    vtx, idx, _, _ = scenes.random_soup(20000, seed=12)
+    nodes = _build(mipt, vtx, idx)
+    rays = random_rays(60000, 99, dtype=mipt.ray_dtype)
+    rays["o"][::2, 3] = 6.0                                      # short rays for occlusion
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx)
+    try:
+        got = sc.trace_closest(rays, mipt.PT_TRACE_MOLLER_TRUMBORE)
+        want = oracle.closest(nodes, vtx, idx, rays, nthreads=8, moller_trumbore=True)
+        assert len(same_hits(got, want)) == 0
+        occ = sc.trace_any(rays)
+        np.testing.assert_array_equal(occ, oracle.any_hit(nodes, vtx, idx, rays, nthreads=8))
+        assert 0.05 < occ.mean() < 0.95
+    finally:
+        sc.close()
+
+
+def test_int_bits_links_on_device(mipt, oracle, scenes, gpu_ctx):
+    vtx, idx, _, _ = scenes.random_soup(4000, seed=5)
+    lb = mipt.mesh_leaf_bounds(vtx, idx)
+    nf = mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": "sah"}))
+    ni = mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": "sah", "mipt.link_encoding": "int"}))
+    rays = random_rays(50000, 6, dtype=mipt.ray_dtype)
+    want = oracle.closest(nf, vtx, idx, rays, nthreads=8)
+    sc = mipt.Scene(gpu_ctx, ni, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
+    try:
+        for flags in (mipt.PT_TRACE_EXACT_ORDER, mipt.PT_TRACE_DEFAULT):
+            assert len(same_hits(sc.trace_closest(rays, flags), want)) == 0
+    finally:
+        sc.close()
+
+
+def test_deep_tree_overflows_the_lds_stack_safely(mipt, oracle, gpu_ctx):
+    """A chain-shaped tree (every split peels one triangle) is deeper than the LDS stack;
+    such rays are handed to the stackless kernel and still match."""
+    n = 200
+    k = np.arange(n, dtype=np.float64)
+    x = 1.5 ** np.minimum(k, 60) + k          # spacing grows so SAH keeps peeling one off
+    tri = np.array([[0, -1, -1], [0, 1, -1], [0, 0, 1]], dtype=np.float64) * 0.4
+    vtx = (tri[None] + np.stack([x, 0 * x, 0 * x], 1)[:, None]).reshape(-1, 3).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+    nodes = _build(mipt, vtx, idx)
+    rays = np.zeros(2 * n, dtype=mipt.ray_dtype)
+    rays["o"][:n] = [(-5, 0, 0, 1e30)] * n            # along the chain: every box is entered
+    rays["d"][:n, 0] = 1
+    rays["o"][n:, 0] = x.astype(np.float32) + 0.3     # and from the far end backwards
+    rays["o"][n:, 3] = 1e30
+    rays["d"][n:, 0] = -1
+    _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays)
+
+
+def test_empty_and_error_paths(mipt, scenes, gpu_ctx):
+    vtx, idx, _, _ = scenes.fallback_quad()
+    nodes = _build(mipt, vtx, idx)
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx)
+    try:
+        assert sc.trace_closest(np.zeros(0, dtype=mipt.ray_dtype)).shape == (0,)
+        assert sc.trace_any(np.zeros(0, dtype=mipt.ray_dtype)).shape == (0,)
+    finally:
+        sc.close()
+    with pytest.raises(mipt.MiptError):
+        mipt.Scene(gpu_ctx, nodes[:-1], vtx, idx)                 # truncated node array
+    with pytest.raises(mipt.MiptError, match="outside the vertex buffer"):
+        mipt.Scene(gpu_ctx, nodes, vtx[:3], idx)
+    with pytest.raises(mipt.MiptError, match="out of range"):
+        mipt.Context(10 ** 6)
+
+
+def test_sponza_class_scene_primary_and_secondary(mipt, oracle, scenes, gpu_ctx):
+    """262,144-triangle stand-in: 1/16 of a 1080p frame of primary rays plus incoherent
+    surface rays, bit-exact; and the work counters the bench's roofline uses are sane."""
+    vtx, idx, _, _ = scenes.atrium()
+    nodes = _build(mipt, vtx, idx)
+    cam = scenes.atrium_camera()
+    rays = gpu_ctx.raygen(cam, 480, 270)
+    sec = scenes.surface_rays(vtx, idx, 100000, seed=7).astype(mipt.ray_dtype)
+    allrays = np.concatenate([rays, sec])
+    want, cnt = oracle.closest(nodes, vtx, idx, allrays, nthreads=8, counters=True)
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx)
+    try:
+        got, st = sc.trace_closest(allrays, stats=True)
+        assert len(same_hits(got, want)) == 0
+        ex, st_ex = sc.trace_closest(allrays, mipt.PT_TRACE_EXACT_ORDER, stats=True)
+        assert len(same_hits(ex, want)) == 0
+        # the fixed-order kernel does exactly the oracle's work
+        assert (st_ex.box_tests, st_ex.tri_tests) == (cnt.box_tests, cnt.tri_tests)
+        # the ordered kernel does several times less
+        assert st.box_tests < cnt.box_tests / 2 and st.tri_tests < cnt.tri_tests
+        print(f"atrium: oracle {cnt.box_tests / len(allrays):.1f} box + "
+              f"{cnt.tri_tests / len(allrays):.1f} tri tests/ray; ordered "
+              f"{st.box_tests / len(allrays):.1f} + {st.tri_tests / len(allrays):.1f}; "
+              f"ties {st.tie_rays}")
+    finally:
+        sc.close()

@@ -1,0 +1,192 @@
+"""Host side of the boundary, on the CPU: builder, linearizer, options, OBJ reader.
+The product's skip-link arrays are checked structurally, against the oracle's linearizer on
+the same tree, and functionally (oracle traversal over product nodes == linear scan)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import random_rays, same_hits
+
+
+def _tree_arrays_from_nodes(nodes):
+    """Recover (left, right, prim) per node from a skip-link array (pre-order numbering)."""
+    n = nodes.shape[0]
+    payload, link = nodes["pmin"][:, 3].astype(np.int64), nodes["pmax"][:, 3].astype(np.int64)
+    left = np.full(n, -1, np.int32)
+    right = np.full(n, -1, np.int32)
+    prim = np.full(n, -1, np.int32)
+    for i in range(n):
+        if payload[i] == -1:
+            left[i], right[i] = i + 1, link[i + 1]
+        else:
+            prim[i] = payload[i]
+    return left, right, prim
+
+
+@pytest.mark.parametrize("builder", ["sah", "median"])
+@pytest.mark.parametrize("n_tri,seed", [(1, 0), (2, 1), (5, 2), (333, 3), (5000, 4)])
+def test_build_bvh_structure_and_traversal(mipt, oracle, scenes, n_tri, seed, builder):
+    vtx, idx, _, _ = scenes.random_soup(n_tri, seed=seed)
+    lb = mipt.mesh_leaf_bounds(vtx, idx)
+    np.testing.assert_array_equal(lb.view(np.uint32), oracle.mesh_leaf_bounds(vtx, idx).view(np.uint32))
+    nodes = mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": builder}))
+    assert nodes.shape[0] == 2 * n_tri - 1
+    mipt.validate_bvh(nodes, n_tri)
+    payload, link = nodes["pmin"][:, 3], nodes["pmax"][:, 3]
+    leaf = payload != -1.0
+    assert sorted(payload[leaf].astype(int)) == list(range(n_tri))
+    assert link[0] == -1.0
+    # leaf boxes = inflated triangle boxes, bit for bit (bvh_builder.cpp:53-59)
+    infl = oracle.inflate(lb)
+    li = np.nonzero(leaf)[0]
+    t = payload[li].astype(int)
+    np.testing.assert_array_equal(nodes["pmin"][li, :3], infl["pmin"][t, :3])
+    np.testing.assert_array_equal(nodes["pmax"][li, :3], infl["pmax"][t, :3])
+    # inner boxes = union of their children's
+    left, right, _ = _tree_arrays_from_nodes(nodes)
+    for i in np.nonzero(~leaf)[0][:200]:
+        lo = np.minimum(nodes["pmin"][left[i], :3], nodes["pmin"][right[i], :3])
+        hi = np.maximum(nodes["pmax"][left[i], :3], nodes["pmax"][right[i], :3])
+        np.testing.assert_array_equal(nodes["pmin"][i, :3], lo)
+        np.testing.assert_array_equal(nodes["pmax"][i, :3], hi)
+    # the reference traversal over these nodes finds what a linear scan finds
+    from oracle.oracle import ray_dtype
+    rays = random_rays(3000, seed + 7, dtype=ray_dtype)
+    a = oracle.closest(nodes, vtx, idx, rays, nthreads=4)
+    b = oracle.brute_closest(vtx, idx, rays, nthreads=4)
+    assert len(same_hits(a, b)) == 0
+
+
+def test_linearizer_matches_oracle_on_same_tree(mipt, oracle, scenes):
+    """PlainBvhTranslator::Process restated twice (product C++ and oracle C) over one topology."""
+    vtx, idx, _, _ = scenes.random_soup(777, seed=21)
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+    left, right, prim = _tree_arrays_from_nodes(nodes)
+    bounds = nodes.copy()
+    bounds["pmin"][:, 3] = 0
+    bounds["pmax"][:, 3] = 0
+    # shuffle the node numbering so neither side can rely on the input already being pre-order
+    rng = np.random.default_rng(5)
+    n = nodes.shape[0]
+    perm = np.concatenate([[0], 1 + rng.permutation(n - 1)])      # new position of old node i
+    inv = np.argsort(perm)
+    b2, l2, r2, p2 = bounds[inv], left[inv], right[inv], prim[inv]
+    l2 = np.where(l2 >= 0, perm[np.maximum(l2, 0)], -1).astype(np.int32)
+    r2 = np.where(r2 >= 0, perm[np.maximum(r2, 0)], -1).astype(np.int32)
+    got = mipt.linearize(b2, l2, r2, p2)
+    want = oracle.linearize(b2, l2, r2, p2)
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+    np.testing.assert_array_equal(got.view(np.uint32), nodes.view(np.uint32))
+
+
+def test_build_is_deterministic_across_thread_counts(mipt, scenes):
+    vtx, idx, _, _ = scenes.random_soup(70000, seed=3)
+    lb = mipt.mesh_leaf_bounds(vtx, idx)
+    a = mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": "sah", "mipt.num_threads": 1}))
+    b = mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": "sah", "mipt.num_threads": 8}))
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_degenerate_inputs(mipt, oracle):
+    # all triangles identical: centroid bounds are a point -> index-median fallback
+    vtx = np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (9, 1))
+    idx = np.arange(27, dtype=np.int32).reshape(-1, 3)
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+    mipt.validate_bvh(nodes, 9)
+    # zero-area triangle (a point) still gets a leaf
+    vtx = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [5, 5, 5]], np.float32)
+    idx = np.array([[0, 1, 2], [3, 3, 3]], np.int32)
+    mipt.validate_bvh(mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx)), 2)
+    # errors: empty input, NaN bounds, index out of range
+    with pytest.raises(mipt.MiptError):
+        mipt.build_bvh(np.zeros(0, dtype=mipt.bbox_dtype))
+    bad = np.zeros(2, dtype=mipt.bbox_dtype)
+    bad["pmin"][0, 0] = np.nan
+    with pytest.raises(mipt.MiptError, match="not finite"):
+        mipt.build_bvh(bad)
+    with pytest.raises(mipt.MiptError, match="outside the vertex buffer"):
+        mipt.mesh_leaf_bounds(vtx, np.array([[0, 1, 9]], np.int32))
+
+
+def test_options_mirror_reference_keys(mipt):
+    opt = mipt.bvh_options()
+    # defaults of src/bvh/bvh_builder.cpp:26-32
+    assert (opt.use_sah, opt.use_splits, opt.max_split_depth, opt.num_bins) == (0, 0, 10, 64)
+    assert (opt.min_overlap, opt.traversal_cost, opt.extra_node_budget) == (
+        pytest.approx(0.05), pytest.approx(10.0), pytest.approx(0.5))
+    opt = mipt.bvh_options(**{"bvh.builder": "sah", "bvh.sah.num_bins": 16,
+                              "bvh.sah.traversal_cost": 4, "bvh.sah.use_splits": 0})
+    assert (opt.use_sah, opt.num_bins, opt.traversal_cost, opt.use_splits) == (1, 16, 4.0, 0)
+    with pytest.raises(mipt.MiptError, match="unknown option"):
+        mipt.bvh_options(**{"bvh.nope": 1})
+    with pytest.raises(mipt.MiptError, match="not a number"):
+        mipt.bvh_options(**{"bvh.sah.num_bins": "many"})
+    # spatial splits are declared but not built
+    lb = np.zeros(2, dtype=mipt.bbox_dtype)
+    lb["pmax"][:, :3] = 1
+    with pytest.raises(mipt.MiptError, match="use_splits"):
+        mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.sah.use_splits": 1}))
+
+
+def test_validate_rejects_broken_arrays(mipt, scenes):
+    vtx, idx, _, _ = scenes.random_soup(50, seed=1)
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx))
+    mipt.validate_bvh(nodes, 50)
+    for mutate in (lambda a: a["pmax"].__setitem__((0, 3), 5.0),            # root must link to -1
+                   lambda a: a["pmax"].__setitem__((3, 3), 1.0),            # backwards link
+                   lambda a: a["pmin"].__setitem__((np.nonzero(a["pmin"][:, 3] != -1)[0][0], 3), 77.0),
+                   lambda a: a["pmin"].__setitem__((5, 0), np.nan)):
+        broken = nodes.copy()
+        mutate(broken)
+        with pytest.raises(mipt.MiptError):
+            mipt.validate_bvh(broken, 50)
+    with pytest.raises(mipt.MiptError):
+        mipt.validate_bvh(nodes[:-1], 50)
+
+
+def test_int_bits_link_encoding(mipt, scenes):
+    """The integer encoding documented at src/bvh/bvh_builder.h:29-33 carries the same tree."""
+    vtx, idx, _, _ = scenes.random_soup(300, seed=2)
+    lb = mipt.mesh_leaf_bounds(vtx, idx)
+    f = mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": "sah"}))
+    i = mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": "sah", "mipt.link_encoding": "int"}))
+    mipt.validate_bvh(i, 300, link_encoding=mipt.PT_LINKS_INT_BITS)
+    np.testing.assert_array_equal(f["pmin"][:, :3], i["pmin"][:, :3])
+    np.testing.assert_array_equal(f["pmin"][:, 3].astype(np.int32), i["pmin"][:, 3].view(np.int32))
+    np.testing.assert_array_equal(f["pmax"][:, 3].astype(np.int32), i["pmax"][:, 3].view(np.int32))
+    assert (i["pmin"][:, 3].view(np.uint32) == 0xFFFFFFFF).sum() == 299
+
+
+def test_obj_reader(mipt, scenes, tmp_path):
+    vtx, idx, mats, mids = scenes.cornell_box()
+    assert vtx.shape == (64, 3) and idx.shape == (32, 3)
+    assert mats.shape[0] == 4 and mids.max() == 3
+    light = mats[mids[10]]           # 6th quad = light
+    np.testing.assert_allclose(light["ke"], [17, 12, 4])
+    np.testing.assert_allclose(mats[mids[6]]["kd"], [0.14, 0.45, 0.091])   # right wall: green
+    # polygons fan-triangulated, negative indices, v/vt/vn forms, no material -> default
+    p = tmp_path / "t.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 2 0\n"
+                 "f 1/1/1 2/2/2 3//3 4 5\nf -5 -4 -3\n")
+    m = mipt.Mesh(str(p))
+    np.testing.assert_array_equal(m.idx, [[0, 1, 2], [0, 2, 3], [0, 3, 4], [0, 1, 2]])
+    assert m.materials.shape[0] == 1 and (m.material_ids == 0).all()
+    # "scale model into unit cube" (src/main.cpp:865-880)
+    m = mipt.Mesh(str(p), normalize=True)
+    ext = m.vtx.max(axis=0) - m.vtx.min(axis=0)
+    assert ext.max() == pytest.approx(1.0) and abs(m.vtx.max(axis=0) + m.vtx.min(axis=0)).max() < 1e-6
+    with pytest.raises(mipt.MiptError, match="cannot open"):
+        mipt.Mesh(str(tmp_path / "missing.obj"))
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nf 1 2 3\n")
+    with pytest.raises(mipt.MiptError, match="out of range"):
+        mipt.Mesh(str(tmp_path / "bad.obj"))
+
+
+def test_atrium_stand_in_counts(scenes):
+    vtx, idx, mats, mids = scenes.atrium(65536, seed=42)
+    assert idx.shape == (65536, 3) and mids.shape == (65536,)
+    assert idx.max() < vtx.shape[0] and np.isfinite(vtx).all()
+    v2, i2, _, _ = scenes.atrium(65536, seed=42)
+    np.testing.assert_array_equal(vtx, v2)
+    np.testing.assert_array_equal(idx, i2)
