@@ -60,7 +60,8 @@ def main():
     nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
     build_s = time.time() - t0
     ctx = mipt.Context(local_rank)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream()          # the library's work and the timing events share it
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     scene = mipt.Scene(ctx, nodes, vtx, idx, mats, mids)
 

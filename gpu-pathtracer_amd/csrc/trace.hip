@@ -150,6 +150,17 @@ __global__ __launch_bounds__(kBlock) void k_trace_ordered(DeviceScene s, const p
 
         int sp = 0;
         int32_t cur = 0;             // >= 0: two-child node, < 0: ~triangle slot
+        // Non-finite rays and zero directions follow whatever the shader's arithmetic
+        // makes of them (a NaN distance is "accepted" once and then culls everything):
+        // that depends on the visiting order, so they go to the fixed-order kernel.
+        {
+            const float chk = ((ro.x + ro.y) + (ro.z + rd.x)) + (rd.y + rd.z);
+            if (!(fabsf(chk) < INFINITY) || !(tmax == tmax) ||
+                (rd.x == 0.f && rd.y == 0.f && rd.z == 0.f)) {
+                tie = true;
+                cur = kSentinel;
+            }
+        }
         while (cur != kSentinel) {
             while (cur >= 0) {
                 const float4 *np = s.wnodes + 4 * (int64_t)cur;
@@ -187,6 +198,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_ordered(DeviceScene s, const p
                 float h0, h1, h2, ht;
                 if (intersect_triangle_watertight(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z,
                                                   q1.w, q2.x, bound, h0, h1, h2, ht)) {
+                    if (!(ht == ht)) {   // NaN distance out of finite inputs: as above
+                        tie = true;
+                        cur = kSentinel;
+                        break;
+                    }
                     if (primid < 0 || ht < tbest) {
                         if (primid >= 0) second = fminf(second, tbest);
                         tbest = ht; b0 = h0; b1 = h1; b2 = h2;

@@ -312,8 +312,10 @@ def surface_rays(vtx, idx, n_rays: int, seed: int = 7, tmax: float = 1e30):
     cosine-distributed directions about it.  Returns a ray_dtype array."""
     from . import ray_dtype
     rng = np.random.default_rng(seed)
-    t = rng.integers(0, idx.shape[0], size=n_rays)
-    a, b, c = (vtx[idx[t, k]].astype(np.float64) for k in range(3))
+    va, vb, vc = (vtx[idx[:, k]].astype(np.float64) for k in range(3))
+    valid = np.nonzero(np.linalg.norm(np.cross(vb - va, vc - va), axis=1) > 1e-12)[0]
+    t = valid[rng.integers(0, valid.shape[0], size=n_rays)]   # skip zero-area triangles
+    a, b, c = va[t], vb[t], vc[t]
     u, v = rng.random(n_rays), rng.random(n_rays)
     flip = u + v > 1
     u[flip], v[flip] = 1 - u[flip], 1 - v[flip]

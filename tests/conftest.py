@@ -56,9 +56,14 @@ def random_rays(n, seed, extent=14.0, tmax=1e30, dtype=None):
     return rays
 
 
-def same_hits(a, b):
-    """Bit-exact comparison of two hit arrays; returns indices that differ."""
+def same_hits(a, b, nan_equal=False):
+    """Bit-exact comparison of two hit arrays; returns indices that differ.  With nan_equal,
+    any NaN matches any NaN (x86 and gfx950 generate different NaN sign/payload bits)."""
     bad = (a["shapeid"] != b["shapeid"]) | (a["primid"] != b["primid"])
     bad |= (a["padding"] != b["padding"]).any(axis=1)
-    bad |= (a["uvwt"].view(np.uint32) != b["uvwt"].view(np.uint32)).any(axis=1)
+    ua, ub = a["uvwt"].view(np.uint32).copy(), b["uvwt"].view(np.uint32).copy()
+    if nan_equal:
+        ua[np.isnan(a["uvwt"])] = 0x7FC00000
+        ub[np.isnan(b["uvwt"])] = 0x7FC00000
+    bad |= (ua != ub).any(axis=1)
     return np.nonzero(bad)[0]
