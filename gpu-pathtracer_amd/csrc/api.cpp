@@ -406,19 +406,10 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
     const bool fixup = (flags & PT_TRACE_NO_TIE_FIXUP) == 0;
     HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(DeviceTraceCounters), st));
     if (exact) {
-        launch_trace_skiplink(st, scene->dev, rays_dev, hits_dev, n, nullptr, nullptr, mt,
+        launch_trace_skiplink(st, scene->dev, rays_dev, hits_dev, n, mt,
                               count ? ctx->counters : nullptr);
     } else {
-        uint32_t *tie_list = nullptr;
-        if (fixup) {
-            int rc = ctx->tie_list.reserve(sizeof(uint32_t) * (size_t)std::max<uint64_t>(n, 1));
-            if (rc != PT_OK) return rc;
-            tie_list = (uint32_t *)ctx->tie_list.ptr;
-        }
-        launch_trace_ordered(st, scene->dev, rays_dev, hits_dev, n, tie_list, ctx->counters, count);
-        if (fixup)
-            launch_trace_skiplink(st, scene->dev, rays_dev, hits_dev, n, tie_list,
-                                  &ctx->counters->tie_count, false, nullptr);
+        launch_trace_ordered(st, scene->dev, rays_dev, hits_dev, n, fixup, ctx->counters, count);
     }
     HIP_CHECK(hipGetLastError());
     if (stats) {

@@ -31,13 +31,11 @@ struct pt_context {
     bool external_stream = false;
     bool kernel_timing = false;
     mipt::DeviceTraceCounters *counters = nullptr;
-    mipt::DeviceBuffer tie_list;    // ray indices handed to the fixed-order kernel
     mipt::DeviceBuffer io_rays;     // staging for the host-pointer entry points
     mipt::DeviceBuffer io_hits;
     mipt::DeviceBuffer render_ws;   // wavefront state of pt_render
 
     void release_all() {
-        tie_list.release();
         io_rays.release();
         io_hits.release();
         render_ws.release();

@@ -32,16 +32,15 @@ struct DeviceTraceCounters {
     unsigned int _pad;
 };
 
-// Closest hit in the reference's fixed skip-link order.  If list != nullptr the
-// kernel processes rays list[0 .. *list_count) instead of 0 .. n.
+// Closest hit in the reference's fixed skip-link order.
 void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
-                           uint64_t n, const uint32_t *list, const unsigned int *list_count,
-                           bool moller_trumbore, DeviceTraceCounters *counters);
+                           uint64_t n, bool moller_trumbore, DeviceTraceCounters *counters);
 
-// Closest hit by ordered two-child traversal; rays whose result could depend on
-// the visiting order are appended to tie_list / counters->tie_count.
+// Closest hit by ordered two-child traversal.  Rays whose result could depend on the
+// visiting order are counted in counters->tie_count and, when fixup is set, re-resolved
+// in the fixed order inside the same kernel.
 void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
-                          uint64_t n, uint32_t *tie_list, DeviceTraceCounters *counters,
+                          uint64_t n, bool fixup, DeviceTraceCounters *counters,
                           bool count_work);
 
 void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, int32_t *occluded,
