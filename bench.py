@@ -1,15 +1,20 @@
 """Benchmark of the path-tracing hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2]): Sponza-class scene (262,144-triangle procedural
-stand-in, seed 42), 1920x1080, Lambert+GGX, depth 8.  A step is one pass of the hot path
-over one batch of camera samples (``--spp-per-step`` samples per pixel through all
-bounces).  Inputs are resident in HBM before the timed region.  One process per GPU; ranks
-render disjoint sample ranges of the same frame (weak scaling) and the film is reduced
-over RCCL after the timed steps.
+Workload (BASELINE.json configs[2], the one the headline metric is quoted on): Sponza-class
+scene (262,144-triangle procedural stand-in for Crytek Sponza, seed 42 -- no assets exist
+offline), 1920x1080, Lambert+GGX materials, max depth 8, Russian roulette from bounce 3.
+A step is one pass of the whole hot path -- raygen, (extend, shade) x depth, accumulate --
+over one batch of --spp-per-step samples per pixel; 256 spp is 256/spp-per-step steps.
+Scene, BVH and film are resident in HBM before the timed region.
 
-Prints one JSON line (rank 0).  `value` = rays traced by all ranks / wall time (Mrays/s).
+Multi-GPU: one process per GPU, scene replicated, ranks render disjoint sample ranges of the
+same frame (weak scaling: work per rank fixed) with no collective on the data path; the film
+is summed once over RCCL (reduce to rank 0) at the end of the timed region.
+
+Prints one JSON line (rank 0): value = rays traced by all ranks / wall time, in Mrays/s.
 """
 import argparse
 import json
@@ -28,13 +33,16 @@ import numpy as np  # noqa: E402
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tris", type=int, default=262144)
-    ap.add_argument("--cpu-baseline-rays", type=int, default=400000)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--spp-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-scale", type=int, default=2,
+                    help="the CPU baseline renders the frame at 1/scale resolution in x and y")
     return ap.parse_args()
 
 
@@ -49,125 +57,137 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         "python -m torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    # ---- scene (host), BVH (host), upload ---------------------------------------------
+    # ---- host side: scene, BVH; then upload ------------------------------------------------
     vtx, idx, mats, mids = scenes.atrium(args.tris, seed=42)
     t0 = time.time()
     nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
     build_s = time.time() - t0
     ctx = mipt.Context(local_rank)
-    stream = torch.cuda.Stream()          # the library's work and the timing events share it
+    stream = torch.cuda.Stream()          # the library's kernels and the timing share this stream
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     scene = mipt.Scene(ctx, nodes, vtx, idx, mats, mids)
-
-    W, H = args.width, args.height
-    n_px = W * H
+    W, H, spp = args.width, args.height, args.spp_per_step
     cam = scenes.atrium_camera(W / H)
-    rays_p = torch.empty((n_px, 8), dtype=torch.float32, device="cuda")
-    mipt._check(mipt.lib.pt_raygen_device(ctx._h, cam, W, H, rays_p.data_ptr()))
-    sec_host = scenes.surface_rays(vtx, idx, n_px, seed=7 + rank)
-    rays_s = torch.from_numpy(sec_host.view(np.float32).reshape(-1, 8)).cuda()
-    hits = torch.empty((n_px, 8), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
+    film_t = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    film = mipt.Film(ctx, W, H, device_ptr=film_t.data_ptr())
+    sky = (0.55, 0.65, 0.8)
 
-    def step():
-        scene.trace_closest_device(rays_p.data_ptr(), n_px, hits.data_ptr())
-        scene.trace_closest_device(rays_s.data_ptr(), n_px, hits.data_ptr())
-        return 2 * n_px
+    def params(step, flags=0):
+        # rank r renders samples [(step*world + r)*spp, +spp) of every pixel
+        return mipt.render_params(W, H, sample_begin=(step * world + rank) * spp, sample_count=spp,
+                                  max_depth=args.depth, seed=42, rr_start_depth=3, background=sky,
+                                  flags=flags)
 
-    # ---- work per ray (not timed): counted variant of the same kernels ------------------
-    st_p = scene.trace_closest_device_counted(rays_p.data_ptr(), n_px, hits.data_ptr())
-    st_s = scene.trace_closest_device_counted(rays_s.data_ptr(), n_px, hits.data_ptr())
-    n_box = (st_p.box_tests + st_s.box_tests) / (2 * n_px)
-    n_tri = (st_p.tri_tests + st_s.tri_tests) / (2 * n_px)
-    bytes_per_ray = 32.0 * n_box + 48.0 * n_tri + 64.0
+    # ---- work per ray (untimed): the same kernels with their test counters compiled in ------
+    st = mipt.render(ctx, scene, cam, params(0, mipt.PT_RENDER_COUNT_WORK), film, stats=True)
+    rays0 = st.rays_primary + st.rays_bounce
+    n_box, n_tri = st.box_tests / rays0, st.tri_tests / rays0
+    bytes_per_ray = 32.0 * n_box + 48.0 * n_tri + 64.0        # reference-layout bytes per ray
+    film.clear()
 
-    for _ in range(args.warmup):
-        step()
+    ctx.set_kernel_timing(True)
+    for k in range(args.warmup):
+        mipt.render(ctx, scene, cam, params(1000 + k), film, stats=True)
+    film.clear()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
-    rays_done = 0
-    for _ in range(args.steps):
-        rays_done += step()
-    ev1.record(stream)
+    rays = paths = ties = launches = 0
+    extend_ms = 0.0
+    for k in range(args.steps):
+        st = mipt.render(ctx, scene, cam, params(k), film, stats=True)
+        rays += st.rays_primary + st.rays_bounce
+        paths += st.paths
+        ties += st.tie_rays
+        launches += st.extend_launches
+        extend_ms += st.extend_ms
+    if world > 1:
+        dist.reduce(film_t, dst=0, op=dist.ReduceOp.SUM)       # frame assembly over RCCL
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1)
 
-    t_all = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    r_all = torch.tensor([float(rays_done)], dtype=torch.float64, device="cuda")
+    agg = torch.tensor([elapsed, float(rays), float(paths)], dtype=torch.float64, device="cuda")
     if world > 1:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-        dist.all_reduce(r_all, op=dist.ReduceOp.SUM)
-    elapsed = float(t_all.item())
-    total_rays = float(r_all.item())
+        mx = agg.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0].item())
+    total_rays, total_paths = float(agg[1].item()), float(agg[2].item())
 
     if rank == 0:
-        launches = 2 * args.steps
-        avg_launch_s = kernel_ms * 1e-3 / launches
-        achieved = bytes_per_ray * n_px / avg_launch_s / 1e9
+        img = film_t[..., :3] / film_t[..., 3:].clamp(min=1)
+        achieved = bytes_per_ray * rays / (extend_ms * 1e-3) / 1e9
         out = {
-            "metric": "Mrays/s (primary+bounce), Sponza-class 1080p",
+            "metric": "Mrays/s (primary+bounce), Sponza 1080p depth 8",
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "atrium stand-in for Crytek Sponza, %d tris, %dx%d, closest-hit "
-                                   "of primary rays + equal count of incoherent surface rays"
-                                   % (args.tris, W, H),
-                       "rays_per_step_per_gpu": 2 * n_px, "bvh_build_s": round(build_s, 3)},
+            "msamples_per_s": total_paths / elapsed / 1e6,
+            "config": {"workload": "Sponza-class atrium stand-in (%d tris, seed 42), %dx%d, "
+                                   "Lambert+GGX, max depth %d, %d spp per step per GPU; full "
+                                   "wavefront path tracer (raygen, extend, shade, accumulate)"
+                                   % (args.tris, W, H, args.depth, spp),
+                       "rays_per_step_per_gpu": rays / args.steps,
+                       "samples_per_pixel_total": args.steps * spp * world,
+                       "bvh_build_s": round(build_s, 3),
+                       "sharding": "sample ranges per rank, RCCL reduce of the film at the end"},
             "nodes_per_ray": n_box, "tris_per_ray": n_tri, "bytes_per_ray": bytes_per_ray,
-            "tie_rays_per_step": int(st_p.tie_rays + st_s.tie_rays),
+            "tie_rays": int(ties), "mean_radiance": float(img.mean().item()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
-                         "kernel": "k_trace_ordered", "avg_launch_ms": avg_launch_s * 1e3},
+                         "kernel": "k_pt_extend", "launches": int(launches),
+                         "avg_launch_ms": extend_ms / max(launches, 1),
+                         "kernel_time_share": extend_ms * 1e-3 / elapsed,
+                         "note": "algorithmic reference-layout bytes; the 34 MB scene is cache "
+                                 "resident, so this is not HBM traffic"},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(nodes, vtx, idx, rays_p, rays_s, args.cpu_baseline_rays)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(args, nodes, vtx, idx, mats, mids, sky)
+        print(json.dumps(out), flush=True)
+    film.close()
     scene.close()
     ctx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(nodes, vtx, idx, rays_p, rays_s, n_sample):
-    """The oracle's IntersectSceneClosest (reference skip-link order) over the product's BVH,
-    on every host core this process may use, on an evenly strided sample of the step's rays."""
+def cpu_baseline(args, nodes, vtx, idx, mats, mids, sky):
+    """The CPU restatement of the same step -- the reference's IntersectSceneClosest in
+    skip-link order plus this project's shading spec -- over the product's BVH, on the host
+    cores this process may use, on the same frame at reduced resolution."""
+    import mipt
+    from mipt import scenes
     from oracle import oracle
     oracle.build()
     cores = len(os.sched_getaffinity(0))
-    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
-    half = n_sample // 2
-    n = rays_p.shape[0]
-    sel = np.linspace(0, n - 1, half).astype(np.int64)
-    rp = rays_p.cpu().numpy()[sel]
-    rs = rays_s.cpu().numpy()[sel]
-    rays = np.concatenate([rp, rs]).view(oracle.ray_dtype).reshape(-1)
-    oracle.closest(nodes, vtx, idx, rays[:2000], nthreads=cores)
+    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
+    s = max(1, args.cpu_baseline_scale)
+    w, h = args.width // s, args.height // s
+    cam = scenes.atrium_camera(w / h)
+    p = mipt.render_params(w, h, sample_begin=0, sample_count=args.spp_per_step, max_depth=args.depth,
+                           seed=42, rr_start_depth=3, background=sky)
     t0 = time.perf_counter()
-    _, cnt = oracle.closest(nodes, vtx, idx, rays, nthreads=cores, counters=True)
+    _, rays = oracle.render(nodes, vtx, idx, mats, mids, cam, p, nthreads=cores)
     dt = time.perf_counter() - t0
-    return {"value": rays.shape[0] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d rays (every %d-th primary + every %d-th surface ray of one step), "
-                      "%.1f s" % (rays.shape[0], n // half, n // half, dt),
-            "nodes_per_ray": cnt.box_tests / rays.shape[0],
-            "tris_per_ray": cnt.tri_tests / rays.shape[0]}
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "one step of the same frame at %dx%d (1/%d of the pixels), %d spp, depth %d: "
+                      "%d rays in %.1f s" % (w, h, s * s, args.spp_per_step, args.depth, rays, dt)}
 
 
 if __name__ == "__main__":

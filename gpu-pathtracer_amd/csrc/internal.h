@@ -34,8 +34,13 @@ struct pt_context {
     mipt::DeviceBuffer io_rays;     // staging for the host-pointer entry points
     mipt::DeviceBuffer io_hits;
     mipt::DeviceBuffer render_ws;   // wavefront state of pt_render
+    mipt::DeviceBuffer render_counts;   // queue sizes per pass and bounce
+    std::vector<hipEvent_t> events;     // pool for per-kernel timing
 
     void release_all() {
+        render_counts.release();
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        events.clear();
         io_rays.release();
         io_hits.release();
         render_ws.release();
@@ -44,6 +49,13 @@ struct pt_context {
         if (own_stream) (void)hipStreamDestroy(own_stream);
         own_stream = nullptr;
     }
+};
+
+struct pt_film {
+    pt_context *ctx = nullptr;
+    uint32_t width = 0, height = 0;
+    float4 *data = nullptr;
+    bool owned = false;
 };
 
 struct pt_scene {

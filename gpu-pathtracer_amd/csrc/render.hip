@@ -1,0 +1,240 @@
+// Wavefront path tracer for gfx950: raygen -> (extend -> shade)* -> accumulate.
+//
+// Replaces the fragment-shader "megakernel" of the reference (shaders/depth.frag, drawn
+// once per frame at src/main_granite.cpp:419-445) with the loop its author sketched at
+// src/main_granite.cpp:403-415: seed camera rays, intersect, terminate on miss / Russian
+// roulette, accumulate, compact the survivors into the next ray queue.
+//
+// Data layout in HBM: rays and hits are 32-byte records indexed by queue slot (one
+// coalesced 2 KiB run per wavefront); path state (throughput, radiance, key) is indexed by
+// path id and reached through the queue's path-id array.  Queues are compacted with one
+// atomic per wavefront (ballot + prefix count).
+#include "render.h"
+
+#include "pt_camera_math.h"
+#include "pt_shade_math.h"
+#include "pt_traverse.h"
+
+namespace mipt {
+
+namespace {
+
+constexpr int kBlock = kTraceBlock;
+
+__global__ __launch_bounds__(256) void k_pt_raygen(RenderLaunch rl, RenderWorkspace ws,
+                                                   unsigned int *count_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t total = (uint64_t)rl.n_samples * rl.map.n_local;
+    bool valid = false;
+    float4 o = make_float4(0, 0, 0, 0), d = make_float4(0, 0, 0, 0);
+    if (i < total) {
+        const uint32_t j = (uint32_t)(i / rl.map.n_local), lp = (uint32_t)(i % rl.map.n_local);
+        uint32_t x, y;
+        valid = local_to_pixel(rl.map, lp, x, y);
+        if (valid) {
+            const uint32_t key = path_key(rl.p.seed, y * rl.map.width + x, rl.sample0 + j);
+            float jx = 0.5f, jy = 0.5f;
+            if (!(rl.p.flags & (PT_RENDER_PIXEL_CENTRE | PT_RENDER_DEPTH_GREY))) {
+                jx = rnd(key, 0);
+                jy = rnd(key, 1);
+            }
+            make_camera_ray(rl.cam, rl.map.width, rl.map.height, (float)x + jx, (float)y + jy, o, d);
+            ws.key[i] = key;
+            ws.throughput[i] = make_float4(1.f, 1.f, 1.f, 0.f);
+        }
+        ws.radiance[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const uint32_t slot = queue_append(valid, count_out);
+    if (valid) {
+        float4 *r = reinterpret_cast<float4 *>(ws.rays[0] + slot);
+        r[0] = o;
+        r[1] = d;
+        ws.queue[0][slot] = (uint32_t)i;
+    }
+}
+
+// extend: closest hit of every queued ray.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_pt_extend(DeviceScene s, const pt_ray *rays,
+                                                     pt_hit *hits, const unsigned int *count,
+                                                     unsigned int *tie_count,
+                                                     DeviceTraceCounters *work) {
+    __shared__ int32_t s_stack[kTraceStack * kBlock];
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t n = *count;
+    if ((uint64_t)blockIdx.x * kBlock >= n) return;      // whole workgroup past the queue end
+    bool tie = false;
+    unsigned long long nb = 0, nt = 0;
+    if (i < n) {
+        const float4 ro = reinterpret_cast<const float4 *>(rays + i)[0];
+        const float4 rd = reinterpret_cast<const float4 *>(rays + i)[1];
+        float b0, b1, b2, t;
+        int32_t shapeid, primid;
+        tie = closest_hit<COUNT>(s, ro, rd, s_stack + threadIdx.x, true, shapeid, primid, b0, b1,
+                                 b2, t, nb, nt);
+        store_hit(hits, i, shapeid, primid, b0, b1, b2, t);
+    }
+    count_ties(tie, tie_count);
+    if (COUNT) {
+        nb = wave_sum(nb);
+        nt = wave_sum(nt);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&work->box_tests, nb);
+            atomicAdd(&work->tri_tests, nt);
+        }
+    }
+}
+
+// shade: one path vertex per queued hit; survivors are appended to the next queue.
+__global__ __launch_bounds__(256) void k_pt_shade(DeviceScene s, RenderLaunch rl, RenderWorkspace ws,
+                                                  int buf_in, const unsigned int *count_in,
+                                                  unsigned int *count_out, uint32_t bounce) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t n = *count_in;
+    if ((uint64_t)blockIdx.x * 256 >= n) return;
+    bool alive = false;
+    uint32_t pid = 0;
+    V3 no = v3(0, 0, 0), nd = v3(0, 0, 0);
+    if (i < n) {
+        pid = ws.queue[buf_in][i];
+        const int4 hi = reinterpret_cast<const int4 *>(ws.hits + i)[0];
+        const float4 hu = reinterpret_cast<const float4 *>(ws.hits + i)[1];
+        const float4 thr4 = ws.throughput[pid];
+        const V3 thr = v3(thr4.x, thr4.y, thr4.z);
+        float4 L = ws.radiance[pid];
+        if (hi.y < 0) {                                     // left the scene
+            L.x += thr.x * rl.p.background[0];
+            L.y += thr.y * rl.p.background[1];
+            L.z += thr.z * rl.p.background[2];
+        } else {
+            const float4 rd4 = reinterpret_cast<const float4 *>(ws.rays[buf_in] + i)[1];
+            const int64_t t3 = 3 * (int64_t)hi.y;
+            const int32_t i0 = s.idx[t3 + 0], i1 = s.idx[t3 + 1], i2 = s.idx[t3 + 2];
+            const float *p0 = s.vtx + 3 * (int64_t)i0, *p1 = s.vtx + 3 * (int64_t)i1,
+                        *p2 = s.vtx + 3 * (int64_t)i2;
+            const pt_material m = s.materials[s.mat_ids[hi.y]];
+            const ShadeResult r = shade_vertex(
+                m, v3(p0[0], p0[1], p0[2]), v3(p1[0], p1[1], p1[2]), v3(p2[0], p2[1], p2[2]), hu.x,
+                hu.y, hu.z, v3(rd4.x, rd4.y, rd4.z), thr, ws.key[pid], bounce, rl.p.max_depth,
+                rl.p.rr_start_depth, rl.p.ray_offset);
+            L.x += r.emitted.x;
+            L.y += r.emitted.y;
+            L.z += r.emitted.z;
+            alive = r.alive;
+            if (alive) {
+                ws.throughput[pid] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, 0.f);
+                no = r.o;
+                nd = r.d;
+            }
+        }
+        ws.radiance[pid] = L;
+    }
+    const uint32_t slot = queue_append(alive, count_out);
+    if (alive) {
+        float4 *r = reinterpret_cast<float4 *>(ws.rays[buf_in ^ 1] + slot);
+        r[0] = make_float4(no.x, no.y, no.z, 1e30f);
+        r[1] = make_float4(nd.x, nd.y, nd.z, 0.f);
+        ws.queue[buf_in ^ 1][slot] = pid;
+    }
+}
+
+// PT_RENDER_DEPTH_GREY: the reference's per-pixel output (shaders/depth.frag:90-107).
+__global__ __launch_bounds__(256) void k_pt_shade_depth(RenderWorkspace ws,
+                                                        const unsigned int *count) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= *count) return;
+    const uint32_t pid = ws.queue[0][i];
+    ws.radiance[pid] = depth_grey(ws.hits[i].shapeid, ws.hits[i].uvwt[3]);
+}
+
+// accumulate: film[pixel] += radiance of each of the pass's samples, in sample order, so
+// the sum does not depend on how paths were scheduled.
+__global__ __launch_bounds__(256) void k_pt_accumulate(RenderLaunch rl, RenderWorkspace ws,
+                                                       float4 *film, bool overwrite) {
+    const uint32_t lp = blockIdx.x * 256 + threadIdx.x;
+    if (lp >= rl.map.n_local) return;
+    uint32_t x, y;
+    if (!local_to_pixel(rl.map, lp, x, y)) return;
+    const uint64_t px = (uint64_t)y * rl.map.width + x;
+    if (overwrite) {
+        film[px] = ws.radiance[lp];
+        return;
+    }
+    float4 f = film[px];
+    for (uint32_t j = 0; j < rl.n_samples; ++j) {
+        const float4 L = ws.radiance[(uint64_t)j * rl.map.n_local + lp];
+        f.x += L.x;
+        f.y += L.y;
+        f.z += L.z;
+        f.w += 1.0f;
+    }
+    film[px] = f;
+}
+
+// Copy the shard's tiles between the film and a dense buffer (for the RCCL gather).
+__global__ __launch_bounds__(256) void k_film_pack(PixelMap map, float4 *film, float4 *packed,
+                                                   bool unpack) {
+    const uint32_t lp = blockIdx.x * 256 + threadIdx.x;
+    if (lp >= map.n_local) return;
+    uint32_t x, y;
+    if (!local_to_pixel(map, lp, x, y)) {
+        if (!unpack) packed[lp] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const uint64_t px = (uint64_t)y * map.width + x;
+    if (unpack) film[px] = packed[lp];
+    else packed[lp] = film[px];
+}
+
+inline unsigned int blocks(uint64_t n, unsigned int b) { return (unsigned int)((n + b - 1) / b); }
+
+} // namespace
+
+void launch_pt_raygen(hipStream_t st, const RenderLaunch &rl, const RenderWorkspace &ws,
+                      unsigned int *count_out) {
+    const uint64_t total = (uint64_t)rl.n_samples * rl.map.n_local;
+    if (!total) return;
+    hipLaunchKernelGGL(k_pt_raygen, dim3(blocks(total, 256)), dim3(256), 0, st, rl, ws, count_out);
+}
+
+void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspace &ws, int buf,
+                      const unsigned int *count, uint64_t max_rays, unsigned int *tie_count,
+                      DeviceTraceCounters *work) {
+    if (!max_rays) return;
+    if (work)
+        hipLaunchKernelGGL(k_pt_extend<true>, dim3(blocks(max_rays, kBlock)), dim3(kBlock), 0, st,
+                           s, ws.rays[buf], ws.hits, count, tie_count, work);
+    else
+        hipLaunchKernelGGL(k_pt_extend<false>, dim3(blocks(max_rays, kBlock)), dim3(kBlock), 0, st,
+                           s, ws.rays[buf], ws.hits, count, tie_count, work);
+}
+
+void launch_pt_shade(hipStream_t st, const DeviceScene &s, const RenderLaunch &rl,
+                     const RenderWorkspace &ws, int buf_in, const unsigned int *count_in,
+                     unsigned int *count_out, uint64_t max_rays, uint32_t bounce) {
+    if (!max_rays) return;
+    hipLaunchKernelGGL(k_pt_shade, dim3(blocks(max_rays, 256)), dim3(256), 0, st, s, rl, ws, buf_in,
+                       count_in, count_out, bounce);
+}
+
+void launch_pt_shade_depth(hipStream_t st, const RenderWorkspace &ws, const unsigned int *count,
+                           uint64_t max_rays) {
+    if (!max_rays) return;
+    hipLaunchKernelGGL(k_pt_shade_depth, dim3(blocks(max_rays, 256)), dim3(256), 0, st, ws, count);
+}
+
+void launch_pt_accumulate(hipStream_t st, const RenderLaunch &rl, const RenderWorkspace &ws,
+                          float4 *film, bool overwrite) {
+    if (!rl.map.n_local) return;
+    hipLaunchKernelGGL(k_pt_accumulate, dim3(blocks(rl.map.n_local, 256)), dim3(256), 0, st, rl, ws,
+                       film, overwrite);
+}
+
+void launch_film_pack(hipStream_t st, const PixelMap &map, const float4 *film, float4 *packed,
+                      bool unpack) {
+    if (!map.n_local) return;
+    hipLaunchKernelGGL(k_film_pack, dim3(blocks(map.n_local, 256)), dim3(256), 0, st, map,
+                       const_cast<float4 *>(film), packed, unpack);
+}
+
+} // namespace mipt

@@ -1,109 +1,14 @@
-// Ray/scene intersection kernels for gfx950 (wave64).
-//
-//  k_trace_skiplink : IntersectSceneClosest exactly as written
-//                     (shaders/RadeonRays/bvh.glslh:417-456): stackless, fixed order.
-//  k_trace_ordered  : the production closest-hit kernel.  Same boxes, same
-//                     triangle test, same arithmetic, but nearer child first
-//                     with a per-lane stack in LDS, on 64-byte two-child nodes
-//                     and 48-byte triangle records.
-//  k_trace_any      : IntersectSceneAny (shaders/RadeonRays/bvh.glslh:378-414).
-//
-// Why the ordered kernel returns what the fixed-order shader returns.  A
-// triangle can become the shader's answer only if its own leaf box passes the
-// part of the slab test that does not depend on the running nearest distance
-// (an ancestor's box contains the leaf box and rounding is monotonic, so the
-// ancestors then pass too) and its triangle test passes.  That candidate set
-// does not depend on visiting order; only the choice among candidates whose
-// distances are within a few ulp of each other does (the shader accepts an
-// equal-distance triangle visited later, bvh.glslh:268-273).  The ordered kernel
-// keeps its culling distance a factor 1+PT_TIE_WINDOW above its nearest hit, so
-// it sees every candidate in that window; a ray with two or more (a few per
-// million on ordinary scenes) is traversed again, by the same lane, in the
-// shader's fixed order.  A ray with one gets that one from either order.
-#include "kernels.h"
-#include "pt_device_math.h"
+// Stand-alone ray/scene intersection kernels (pt_trace_closest*, pt_trace_any*).
+// The per-ray traversal code lives in pt_traverse.h.
+#include "pt_traverse.h"
 
-#include <limits.h>
+#include <algorithm>
 
 namespace mipt {
 
 namespace {
 
-constexpr int kBlock = PT_TRACE_BLOCK;
-constexpr int kStack = PT_LDS_STACK_ENTRIES;
-constexpr int32_t kSentinel = INT_MIN;
-
-__device__ __forceinline__ void store_hit(pt_hit *hits, uint64_t i, int32_t shapeid, int32_t primid,
-                                          float b0, float b1, float b2, float t) {
-    int4 *p = reinterpret_cast<int4 *>(hits + i);
-    p[0] = make_int4(shapeid, primid, 667, 0);   // bvh.glslh:429-430
-    reinterpret_cast<float4 *>(p)[1] = make_float4(b0, b1, b2, t);
-}
-
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// ------------------------------------------------------------------------
-// IntersectSceneClosest, shaders/RadeonRays/bvh.glslh:417-456, for one ray.
-template <bool MT, bool COUNT>
-__device__ __forceinline__ void traverse_skiplink(const DeviceScene &s, const float4 ro,
-                                                  const float4 rd, int32_t &shapeid,
-                                                  int32_t &primid, float &b0, float &b1, float &b2,
-                                                  float &tbest, unsigned long long &nb,
-                                                  unsigned long long &nt) {
-    const RayPre r = precompute_ray(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
-    b0 = 0.f; b1 = 0.f; b2 = 0.f; tbest = ro.w;           // :423
-    shapeid = -1; primid = -1;                              // :424-425
-    int32_t idx = 0;
-    while (idx != -1) {
-        const float4 lo = s.nodes[2 * (int64_t)idx + 0];
-        const float4 hi = s.nodes[2 * (int64_t)idx + 1];
-        if (COUNT) ++nb;
-        float t0;
-        const int32_t link = decode_link(hi.w, s.link_enc);
-        if (intersect_box(r, lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, tbest, t0)) {
-            const int32_t payload = decode_link(lo.w, s.link_enc);
-            if (payload != -1) {                            // LEAFNODE, :154
-                if (COUNT) ++nt;
-                const int64_t start = payload;              // STARTIDX, :153
-                const int32_t i0 = s.idx[3 * start + 0], i1 = s.idx[3 * start + 1],
-                              i2 = s.idx[3 * start + 2];
-                const float *p0 = s.vtx + 3 * (int64_t)i0, *p1 = s.vtx + 3 * (int64_t)i1,
-                            *p2 = s.vtx + 3 * (int64_t)i2;
-                const float v0x = p0[0], v0y = p0[1], v0z = p0[2];
-                const float v1x = p1[0], v1y = p1[1], v1z = p1[2];
-                const float v2x = p2[0], v2y = p2[1], v2z = p2[2];
-                if (MT) {
-                    float m1, m2, temp;
-                    moller_trumbore(r.ox, r.oy, r.oz, rd.x, rd.y, rd.z, v0x, v0y, v0z, v1x, v1y,
-                                    v1z, v2x, v2y, v2z, m1, m2, temp);
-                    temp = fmaxf(0.0f, temp);               // :191
-                    if (!(m1 < -PT_MT_EPS || m1 > 1.f + PT_MT_EPS || m2 < -PT_MT_EPS ||
-                          m1 + m2 > 1.f + PT_MT_EPS || temp < -PT_MT_EPS ||
-                          temp > tbest + PT_MT_EPS)) {       // :193
-                        b0 = m1; b1 = m2; b2 = 0.f; tbest = temp;   // :199
-                        primid = payload; shapeid = 0;
-                    }
-                } else {
-                    float h0, h1, h2, ht;
-                    if (intersect_triangle_watertight(r, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y,
-                                                      v2z, tbest, h0, h1, h2, ht)) {
-                        b0 = h0; b1 = h1; b2 = h2; tbest = ht;
-                        primid = payload;                   // :344
-                        shapeid = 0;                        // :345
-                    }
-                }
-                idx = link;                                 // :443
-            } else {
-                ++idx;                                      // :448
-            }
-        } else {
-            idx = link;                                     // :453
-        }
-    }
-}
+constexpr int kBlock = kTraceBlock;
 
 template <bool MT, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_skiplink(DeviceScene s, const pt_ray *rays,
@@ -129,130 +34,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_skiplink(DeviceScene s, const 
     }
 }
 
-// ------------------------------------------------------------------------
-// Ordered closest-hit traversal of one ray.  `stack` points at this lane's column of the
-// workgroup's LDS stack (entry e at stack[e * kBlock]).  Sets `tie` when the result could
-// depend on the visiting order (see the note at the top of the file); the caller then
-// re-resolves the ray with traverse_skiplink.
-template <bool COUNT>
-__device__ __forceinline__ void traverse_ordered(const DeviceScene &s, const float4 ro,
-                                                 const float4 rd, int32_t *stack,
-                                                 int32_t &primid, float &b0, float &b1, float &b2,
-                                                 float &tbest, bool &tie, unsigned long long &nb,
-                                                 unsigned long long &nt) {
-    const RayPre r = precompute_ray(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
-    const float tmax = ro.w;
-    b0 = 0.f; b1 = 0.f; b2 = 0.f;
-    tbest = tmax;                // nearest accepted distance (tmax while there is none)
-    float bound = tmax;          // culling distance: tbest widened by the tie window
-    float second = INFINITY;     // nearest distance among the other candidates seen
-    primid = -1;
-    tie = false;
-
-    int sp = 0;
-    int32_t cur = 0;             // >= 0: two-child node, < 0: ~triangle slot
-    // Non-finite rays and zero directions follow whatever the shader's arithmetic makes of
-    // them (a NaN distance is "accepted" once and then culls everything): that depends on
-    // the visiting order, so they are left to the fixed-order traversal.
-    {
-        const float chk = ((ro.x + ro.y) + (ro.z + rd.x)) + (rd.y + rd.z);
-        if (!(fabsf(chk) < INFINITY) || !(tmax == tmax) ||
-            (rd.x == 0.f && rd.y == 0.f && rd.z == 0.f)) {
-            tie = true;
-            cur = kSentinel;
-        }
-    }
-    while (cur != kSentinel) {
-        while (cur >= 0) {
-            const float4 *np = s.wnodes + 4 * (int64_t)cur;
-            const float4 a = np[0], b = np[1], c = np[2];
-            const int4 ch = reinterpret_cast<const int4 *>(np)[3];
-            if (COUNT) nb += 2;
-            float ta, tb;
-            const bool ha = intersect_box(r, a.x, a.y, a.z, a.w, c.x, c.y, bound, ta);
-            const bool hb = intersect_box(r, b.x, b.y, b.z, b.w, c.z, c.w, bound, tb);
-            if (ha && hb) {
-                const bool swap = tb < ta;
-                const int32_t near_c = swap ? ch.y : ch.x;
-                const int32_t far_c = swap ? ch.x : ch.y;
-                if (sp < kStack) {
-                    stack[sp * kBlock] = far_c;
-                    ++sp;
-                    cur = near_c;
-                } else {           // out of stack: leave this ray to the stackless traversal
-                    tie = true;
-                    cur = kSentinel;
-                }
-            } else if (ha || hb) {
-                cur = ha ? ch.x : ch.y;
-            } else if (sp > 0) {
-                --sp;
-                cur = stack[sp * kBlock];
-            } else {
-                cur = kSentinel;
-            }
-        }
-        while (cur < 0 && cur != kSentinel) {
-            const float4 *tp = s.wtris + 3 * (int64_t)(~cur);
-            const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-            if (COUNT) ++nt;
-            float h0, h1, h2, ht;
-            if (intersect_triangle_watertight(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                                              q2.x, bound, h0, h1, h2, ht)) {
-                if (!(ht == ht)) {   // NaN distance out of finite inputs: as above
-                    tie = true;
-                    cur = kSentinel;
-                    break;
-                }
-                if (primid < 0 || ht < tbest) {
-                    if (primid >= 0) second = fminf(second, tbest);
-                    tbest = ht; b0 = h0; b1 = h1; b2 = h2;
-                    primid = __float_as_int(q2.y);
-                    bound = fminf(tbest + tbest * PT_TIE_WINDOW, tmax);
-                } else {
-                    second = fminf(second, ht);
-                }
-            }
-            if (sp > 0) {
-                --sp;
-                cur = stack[sp * kBlock];
-            } else {
-                cur = kSentinel;
-            }
-        }
-    }
-    if (primid >= 0 && second <= tbest + tbest * PT_TIE_WINDOW) tie = true;
-}
-
-// Closest hit of one ray with the reference's result: ordered traversal, and for the rare
-// ray it flags, the fixed-order traversal in the same lane.  Returns whether that happened.
-template <bool COUNT>
-__device__ __forceinline__ bool closest_hit(const DeviceScene &s, const float4 ro, const float4 rd,
-                                            int32_t *stack, bool fixup, int32_t &shapeid,
-                                            int32_t &primid, float &b0, float &b1, float &b2,
-                                            float &t, unsigned long long &nb,
-                                            unsigned long long &nt) {
-    bool tie;
-    traverse_ordered<COUNT>(s, ro, rd, stack, primid, b0, b1, b2, t, tie, nb, nt);
-    shapeid = primid >= 0 ? 0 : -1;
-    if (tie && fixup) {
-        unsigned long long xb = 0, xt = 0;
-        traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt);
-    }
-    return tie;
-}
-
-__device__ __forceinline__ void count_ties(bool tie, DeviceTraceCounters *counters) {
-    const unsigned long long m = __ballot(tie);
-    if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1)
-        atomicAdd(&counters->tie_count, (unsigned int)__popcll(m));
-}
-
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_ordered(DeviceScene s, const pt_ray *rays,
                                                          pt_hit *hits, uint64_t n, bool fixup,
                                                          DeviceTraceCounters *counters) {
-    __shared__ int32_t s_stack[kStack * kBlock];
+    __shared__ int32_t s_stack[kTraceStack * kBlock];
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     unsigned long long nb = 0, nt = 0;
     bool tie = false;
@@ -265,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_ordered(DeviceScene s, const p
                                  b2, t, nb, nt);
         store_hit(hits, i, shapeid, primid, b0, b1, b2, t);
     }
-    count_ties(tie, counters);
+    count_ties(tie, &counters->tie_count);
     if (COUNT) {
         nb = wave_sum(nb);
         nt = wave_sum(nt);
@@ -276,48 +62,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_ordered(DeviceScene s, const p
     }
 }
 
-// ------------------------------------------------------------------------
+// IntersectSceneAny, shaders/RadeonRays/bvh.glslh:378-414 (leaf test :350-375, :289-310).
 __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene s, const pt_ray *rays,
                                                      int32_t *occluded, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 ro = reinterpret_cast<const float4 *>(rays + i)[0];
     const float4 rd = reinterpret_cast<const float4 *>(rays + i)[1];
-    RayPre r;
-    r.ox = ro.x; r.oy = ro.y; r.oz = ro.z;
-    r.ix = 1.0f / rd.x; r.iy = 1.0f / rd.y; r.iz = 1.0f / rd.z;   // bvh.glslh:380
-    int32_t idx = 0, result = 0;
-    while (idx != -1) {
-        const float4 lo = s.nodes[2 * (int64_t)idx + 0];
-        const float4 hi = s.nodes[2 * (int64_t)idx + 1];
-        const int32_t link = decode_link(hi.w, s.link_enc);
-        float t0;
-        if (intersect_box(r, lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, ro.w, t0)) {
-            const int32_t payload = decode_link(lo.w, s.link_enc);
-            if (payload != -1) {
-                const int64_t start = payload;
-                const int32_t i0 = s.idx[3 * start + 0], i1 = s.idx[3 * start + 1],
-                              i2 = s.idx[3 * start + 2];
-                const float *p0 = s.vtx + 3 * (int64_t)i0, *p1 = s.vtx + 3 * (int64_t)i1,
-                            *p2 = s.vtx + 3 * (int64_t)i2;
-                float m1, m2, temp;
-                moller_trumbore(r.ox, r.oy, r.oz, rd.x, rd.y, rd.z, p0[0], p0[1], p0[2], p1[0],
-                                p1[1], p1[2], p2[0], p2[1], p2[2], m1, m2, temp);
-                if (!(m1 < -PT_MT_EPS || m1 > 1.f + PT_MT_EPS || m2 < -PT_MT_EPS ||
-                      m1 + m2 > 1.f + PT_MT_EPS || temp < -PT_MT_EPS ||
-                      temp > ro.w + PT_MT_EPS)) {            // bvh.glslh:301
-                    result = 1;
-                    break;
-                }
-                idx = link;
-            } else {
-                ++idx;
-            }
-        } else {
-            idx = link;
-        }
-    }
-    occluded[i] = result;
+    occluded[i] = occluded_skiplink(s, ro, rd) ? 1 : 0;
 }
 
 inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kBlock - 1) / kBlock); }

@@ -29,7 +29,8 @@ PT_OK, PT_ERR_INVALID, PT_ERR_DEVICE, PT_ERR_UNSUPPORTED, PT_ERR_IO, PT_ERR_NOME
 PT_LINKS_FLOAT_VALUE, PT_LINKS_INT_BITS = 0, 1
 PT_CAMERA_REFERENCE, PT_CAMERA_PINHOLE = 0, 1
 PT_TRACE_DEFAULT, PT_TRACE_EXACT_ORDER, PT_TRACE_MOLLER_TRUMBORE, PT_TRACE_NO_TIE_FIXUP = 0, 1, 2, 4
-PT_RENDER_DEFAULT, PT_RENDER_DEPTH_GREY, PT_RENDER_NEE = 0, 1, 2
+PT_RENDER_DEFAULT, PT_RENDER_DEPTH_GREY, PT_RENDER_NEE, PT_RENDER_PIXEL_CENTRE = 0, 1, 2, 4
+PT_RENDER_COUNT_WORK = 8
 
 # ---------------------------------------------------------------- dtypes
 bbox_dtype = np.dtype([("pmin", np.float32, 4), ("pmax", np.float32, 4)])
@@ -74,7 +75,8 @@ class TraceStats(C.Structure):
 class RenderStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays_primary", C.c_uint64), ("rays_bounce", C.c_uint64),
                 ("rays_shadow", C.c_uint64), ("tie_rays", C.c_uint64),
-                ("extend_launches", C.c_uint64), ("extend_ms", C.c_double)]
+                ("extend_launches", C.c_uint64), ("extend_ms", C.c_double),
+                ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64)]
 
 
 class MiptError(RuntimeError):
@@ -129,6 +131,18 @@ _PROTOS = {
     "pt_raygen": (C.c_int, [_vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, _vp]),
     "pt_raygen_device": (C.c_int, [_vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, _vp]),
     "pt_depth_shade": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "pt_film_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    "pt_film_wrap": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, C.POINTER(_vp)]),
+    "pt_film_clear": (C.c_int, [_vp]),
+    "pt_film_device_ptr": (_vp, [_vp]),
+    "pt_film_read": (C.c_int, [_vp, _vp]),
+    "pt_film_destroy": (C.c_int, [_vp]),
+    "pt_film_packed_size": (C.c_uint64, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "pt_film_pack_tiles": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
+    "pt_film_unpack_tiles": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
+    "pt_render": (C.c_int, [_vp, _vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp,
+                            C.POINTER(RenderStats)]),
+    "pt_render_params_default": (None, [C.POINTER(RenderParams), C.c_uint32, C.c_uint32]),
 }
 for _name, (_res, _args) in _PROTOS.items():
     _fn = getattr(lib, _name)
@@ -335,6 +349,75 @@ class Scene:
 
     def trace_any_device(self, rays_dev: int, n: int, out_dev: int) -> None:
         _check(lib.pt_trace_any_device(self.ctx._h, self._h, rays_dev, n, out_dev))
+
+
+def render_params(width: int, height: int, **kw) -> RenderParams:
+    p = RenderParams()
+    lib.pt_render_params_default(C.byref(p), width, height)
+    for k, v in kw.items():
+        if k == "background":
+            for i in range(3):
+                p.background[i] = float(v[i])
+        else:
+            if not hasattr(p, k):
+                raise AttributeError(f"pt_render_params has no field {k!r}")
+            setattr(p, k, v)
+    return p
+
+
+class Film:
+    """width x height float4 accumulation buffer on the context's GPU.
+
+    ``device_ptr``: wrap caller-owned device memory (e.g. ``tensor.data_ptr()`` of a
+    float32 CUDA tensor of shape [H, W, 4]) instead of allocating."""
+
+    def __init__(self, ctx: Context, width: int, height: int, device_ptr: Optional[int] = None):
+        self.ctx, self.width, self.height = ctx, width, height
+        self._h = _vp()
+        if device_ptr is None:
+            _check(lib.pt_film_create(ctx._h, width, height, C.byref(self._h)))
+        else:
+            _check(lib.pt_film_wrap(ctx._h, width, height, device_ptr, C.byref(self._h)))
+
+    def clear(self) -> None:
+        _check(lib.pt_film_clear(self._h))
+
+    @property
+    def device_ptr(self) -> int:
+        return lib.pt_film_device_ptr(self._h) or 0
+
+    def read(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        _check(lib.pt_film_read(self._h, _ptr(out)))
+        return out
+
+    def packed_size(self, tile_size: int, shard_index: int, shard_count: int) -> int:
+        return int(lib.pt_film_packed_size(self._h, tile_size, shard_index, shard_count))
+
+    def pack_tiles(self, tile_size, shard_index, shard_count, packed_dev: int) -> None:
+        _check(lib.pt_film_pack_tiles(self._h, tile_size, shard_index, shard_count, packed_dev))
+
+    def unpack_tiles(self, tile_size, shard_index, shard_count, packed_dev: int) -> None:
+        _check(lib.pt_film_unpack_tiles(self._h, tile_size, shard_index, shard_count, packed_dev))
+
+    def close(self) -> None:
+        if self._h:
+            lib.pt_film_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render(ctx: Context, scene: "Scene", cam: Camera, params: RenderParams, film: Film,
+           stats: bool = False):
+    st = RenderStats()
+    _check(lib.pt_render(ctx._h, scene._h, C.byref(cam), C.byref(params), film._h,
+                         C.byref(st) if stats else None))
+    return st if stats else None
 
 
 # ---------------------------------------------------------------- camera helpers

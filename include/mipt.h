@@ -93,6 +93,8 @@ typedef struct pt_render_stats {
     uint64_t tie_rays;
     uint64_t extend_launches;
     double   extend_ms;         /* summed device time of the closest-hit kernels, if timing is on */
+    uint64_t box_tests;         /* with PT_RENDER_COUNT_WORK: AABB slab tests ... */
+    uint64_t tri_tests;         /* ... and ray/triangle tests of those kernels */
 } pt_render_stats;
 
 /* ------------------------------------------------------------------------ */
@@ -208,6 +210,43 @@ int pt_raygen_device(pt_context *ctx, const pt_camera *cam, uint32_t width, uint
 
 /* The colour the reference writes per pixel, shaders/depth.frag:90-107. rgba: n*4. */
 int pt_depth_shade(pt_context *ctx, const pt_hit *hits, uint64_t n, float *rgba);
+
+/* ------------------------------------------------------------------------ */
+/* Film and rendering                                                        */
+
+/* The colour attachment of the reference's "path_trace" pass (src/main_granite.cpp:388-400),
+ * as width*height float4 in row-major order from the top-left pixel: rgb = radiance summed
+ * over samples, a = number of samples (the caller divides).  In PT_RENDER_DEPTH_GREY mode it
+ * holds the reference's (grey, grey, grey, 1). */
+int pt_film_create(pt_context *ctx, uint32_t width, uint32_t height, pt_film **out);
+/* Same, over device memory the caller owns (width*height*4 floats, 16-byte aligned), e.g. a
+ * buffer that is also handed to RCCL. */
+int pt_film_wrap(pt_context *ctx, uint32_t width, uint32_t height, float *rgba_dev,
+                 pt_film **out);
+int pt_film_clear(pt_film *film);
+float *pt_film_device_ptr(pt_film *film);
+/* readback_ssbo, src/main_granite.cpp:499-522: blocking copy to host memory. */
+int pt_film_read(pt_film *film, float *rgba);
+int pt_film_destroy(pt_film *film);
+
+/* Number of float4 entries pt_film_pack_tiles writes for this sharding: tiles owned by
+ * shard_index (tile t belongs to shard t % shard_count) times tile_size^2. */
+uint64_t pt_film_packed_size(const pt_film *film, uint32_t tile_size, uint32_t shard_index,
+                             uint32_t shard_count);
+/* Copies the shard's tiles into / out of a dense device buffer, so that ranks can exchange
+ * only the tiles they rendered (one RCCL all-gather) instead of whole frames. */
+int pt_film_pack_tiles(pt_film *film, uint32_t tile_size, uint32_t shard_index,
+                       uint32_t shard_count, float *packed_dev);
+int pt_film_unpack_tiles(pt_film *film, uint32_t tile_size, uint32_t shard_index,
+                         uint32_t shard_count, const float *packed_dev);
+
+/* One frame's worth of work of the "path_trace" pass callback, src/main_granite.cpp:402-451
+ * (bind the scene buffers and the camera, draw): renders params->sample_count samples per
+ * pixel of the tiles this shard owns and adds them to the film.  Asynchronous on the
+ * context's stream unless stats != NULL (then it synchronizes and fills stats). */
+int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
+              const pt_render_params *params, pt_film *film, pt_render_stats *stats);
+void pt_render_params_default(pt_render_params *params, uint32_t width, uint32_t height);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,11 @@
 #define PT_RENDER_DEPTH_GREY 1u
 /* Add next-event estimation (one shadow ray per path vertex). */
 #define PT_RENDER_NEE 2u
+/* Camera samples at pixel centres instead of jittered positions. */
+#define PT_RENDER_PIXEL_CENTRE 4u
+/* Count slab and triangle tests of the closest-hit kernels into pt_render_stats (slower;
+ * for measurement). */
+#define PT_RENDER_COUNT_WORK 8u
 
 #ifdef __cplusplus
 extern "C" {

@@ -157,6 +157,61 @@ def depth_shade(isects) -> np.ndarray:
     return out
 
 
+class ShadeCamera(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("sx", C.c_float), ("c0", C.c_float * 3), ("sy", C.c_float),
+                ("c1", C.c_float * 3), ("mode", C.c_uint32), ("c2", C.c_float * 3), ("pad", C.c_float)]
+
+
+class ShadeParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("sample_begin", C.c_uint32),
+                ("sample_count", C.c_uint32), ("max_depth", C.c_uint32), ("seed", C.c_uint32),
+                ("rr_start_depth", C.c_uint32), ("flags", C.c_uint32), ("tile_size", C.c_uint32),
+                ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+                ("samples_per_pass", C.c_uint32), ("background", C.c_float * 3),
+                ("ray_offset", C.c_float)]
+
+
+material_dtype = np.dtype([("kd", np.float32, 3), ("roughness", np.float32),
+                           ("ks", np.float32, 3), ("_pad0", np.float32),
+                           ("ke", np.float32, 3), ("_pad1", np.float32)])
+
+
+def render(nodes, vtx, idx, materials, material_ids, cam, params, film=None, rect=None,
+           nthreads=1):
+    """CPU restatement of the path tracer.  cam / params: any ctypes structs with the byte
+    layout of ShadeCamera / ShadeParams (the product's pt_camera / pt_render_params have it).
+    Adds into `film` ([H, W, 4] float32) and returns (film, rays_traced)."""
+    L = lib()
+    L.os_render.restype = C.c_uint64
+    L.os_render.argtypes = [C.c_void_p] * 7 + [C.c_uint32] * 4 + [C.c_void_p, C.c_int]
+    nodes, vtx, idx = _c(nodes, bbox_dtype), _c(vtx, np.float32), _c(idx, np.int32)
+    mats, mids = _c(materials, material_dtype), _c(material_ids, np.int32)
+    assert C.sizeof(cam) == C.sizeof(ShadeCamera) and C.sizeof(params) == C.sizeof(ShadeParams)
+    W, H = params.width, params.height
+    if film is None:
+        film = np.zeros((H, W, 4), dtype=np.float32)
+    x0, y0, x1, y1 = rect if rect is not None else (0, 0, W, H)
+    rays = L.os_render(nodes.ctypes.data, vtx.ctypes.data, idx.ctypes.data, mats.ctypes.data,
+                       mids.ctypes.data, C.addressof(cam), C.addressof(params), x0, y0, x1, y1,
+                       film.ctypes.data, nthreads)
+    return film, int(rays)
+
+
+def sincos_2pi(u):
+    L = lib()
+    L.os_sincos_2pi.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    s, c = C.c_float(), C.c_float()
+    L.os_sincos_2pi(u, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def rnd(seed, pixel, sample, dim):
+    L = lib()
+    L.os_rnd.restype = C.c_float
+    L.os_rnd.argtypes = [C.c_uint32] * 4
+    return L.os_rnd(seed, pixel, sample, dim)
+
+
 def camera_from(eye, c0, c1, c2, sx, sy) -> Camera:
     cam = Camera()
     cam.ip00, cam.ip11 = sx, sy

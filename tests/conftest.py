@@ -5,6 +5,13 @@ import sys
 import numpy as np
 import pytest
 
+try:
+    # torch ships its own HIP runtime; loading it before libmipt.so makes both share one,
+    # which the tests that hand torch device pointers to the library rely on.
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(REPO, "gpu-pathtracer_amd"), REPO):
     if p not in sys.path:

@@ -1,0 +1,168 @@
+"""The wavefront path tracer (raygen -> extend -> shade -> accumulate) against its CPU
+restatement, through the C ABI.
+
+Stated tolerance (north star): relative RMSE of radiance after N spp <= 1e-3 at equal seeds.
+Because the shading spec uses only exactly rounded operations in a fixed order, random
+numbers are integer hashes, hits are bit-exact and samples are summed in sample order, the
+tests additionally require the film to be bit-identical and report it if it is not.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_RMSE_TOL = 1e-3
+
+
+def rel_rmse(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(np.sqrt(np.mean(b ** 2)), 1e-30))
+
+
+def _setup(mipt, ctx, scene, builder="sah"):
+    vtx, idx, mats, mids = scene
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": builder}))
+    return nodes, mipt.Scene(ctx, nodes, vtx, idx, mats, mids)
+
+
+def _compare(mipt, oracle, ctx, scene, cam, W, H, exact=True, **kw):
+    vtx, idx, mats, mids = scene
+    nodes, sc = _setup(mipt, ctx, scene)
+    film = mipt.Film(ctx, W, H)
+    try:
+        p = mipt.render_params(W, H, **kw)
+        st = mipt.render(ctx, sc, cam, p, film, stats=True)
+        got = film.read()
+        want, rays = oracle.render(nodes, vtx, idx, mats, mids, cam, p, nthreads=8)
+        err = rel_rmse(got[..., :3], want[..., :3])
+        assert err <= REL_RMSE_TOL, f"relative RMSE {err}"
+        np.testing.assert_array_equal(got[..., 3], want[..., 3])
+        assert st.rays_primary + st.rays_bounce == rays
+        n_diff = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+        print(f"rel-RMSE {err:.3e}, {n_diff} differing words of {got.size}, "
+              f"{st.rays_primary} primary + {st.rays_bounce} bounce rays, {st.tie_rays} ties")
+        if exact:
+            assert n_diff == 0, f"film differs from the CPU restatement in {n_diff} words"
+        return got, st
+    finally:
+        film.close()
+        sc.close()
+
+
+def cornell_camera(mipt, aspect=1.0):
+    return mipt.look_at_camera((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), fovy_deg=39.3, aspect=aspect)
+
+
+def test_cornell_lambert_depth4(mipt, oracle, scenes, gpu_ctx):
+    """Baseline config #2 at reduced size: Cornell box, Lambertian, max depth 4, seed 1."""
+    got, st = _compare(mipt, oracle, gpu_ctx, scenes.cornell_box(), cornell_camera(mipt), 128, 128,
+                       sample_count=16, max_depth=4, seed=1)
+    img = got[..., :3] / got[..., 3:]
+    assert 0.02 < img.mean() < 2.0
+    assert st.paths == 128 * 128 * 16
+
+
+def test_passes_do_not_change_the_result(mipt, oracle, scenes, gpu_ctx):
+    """Samples in flight per pass is a scheduling knob: 1, 3 or all at once give one film."""
+    scene = scenes.cornell_box()
+    cam = cornell_camera(mipt)
+    films = [_compare(mipt, oracle, gpu_ctx, scene, cam, 64, 48, sample_count=7, max_depth=5,
+                      rr_start_depth=2, samples_per_pass=spp)[0] for spp in (1, 3, 0)]
+    for f in films[1:]:
+        np.testing.assert_array_equal(f.view(np.uint32), films[0].view(np.uint32))
+
+
+def test_atrium_lambert_ggx_depth8(mipt, oracle, scenes, gpu_ctx):
+    """Baseline config #3 at reduced size: Sponza-class stand-in, Lambert + GGX, depth 8."""
+    scene = scenes.atrium(65536, seed=42)
+    cam = scenes.atrium_camera(160 / 90)
+    got, st = _compare(mipt, oracle, gpu_ctx, scene, cam, 160, 90, sample_count=4, max_depth=8,
+                       seed=42, background=(0.3, 0.35, 0.4))
+    assert st.rays_bounce > 2 * st.rays_primary
+
+
+def test_furnace_on_gpu(mipt, oracle, scenes, gpu_ctx):
+    from test_shade_oracle import _box_scene
+    cam = mipt.look_at_camera((0.1, 0.2, -0.3), (0.5, 0.3, 1.0), fovy_deg=70.0)
+    got, _ = _compare(mipt, oracle, gpu_ctx, _box_scene(scenes, (0.5, 0.5, 0.5), (1, 1, 1)), cam, 40, 24,
+                      sample_count=3, max_depth=6, rr_start_depth=99)
+    np.testing.assert_allclose(got[..., :3] / got[..., 3:], sum(0.5 ** k for k in range(6)), rtol=1e-6)
+
+
+def test_reference_depth_grey_frame(mipt, oracle, scenes, gpu_ctx):
+    """PT_RENDER_DEPTH_GREY with the reference camera is the frame the reference draws:
+    depth.frag raygen -> IntersectSceneClosest -> smoothstep grey."""
+    vtx, idx, mats, mids = scenes.random_soup(3000, seed=8, extent=60.0, size=12.0)
+    vtx = vtx + np.float32([0, 40, 0])
+    cam = mipt.look_at_camera((0.0, 0.0, -10.0), (0, 0, 0), fovy_deg=60.0, aspect=4 / 3,
+                              mode=mipt.PT_CAMERA_REFERENCE)
+    got, _ = _compare(mipt, oracle, gpu_ctx, (vtx, idx, mats, mids), cam, 200, 150,
+                      flags=mipt.PT_RENDER_DEPTH_GREY)
+    assert (got[..., 3] == 1).all() and got[..., 0].max() > 0
+
+
+def test_tile_and_sample_sharding(mipt, oracle, scenes, gpu_ctx):
+    """What N ranks do: disjoint tiles (bit-identical to one rank after assembling) or disjoint
+    sample ranges (identical up to the order of the final per-pixel sum)."""
+    scene = scenes.cornell_box()
+    cam = cornell_camera(mipt, 100 / 76)
+    W, H = 100, 76                         # not a multiple of the tile size
+    nodes, sc = _setup(mipt, gpu_ctx, scene)
+    try:
+        full = mipt.Film(gpu_ctx, W, H)
+        mipt.render(gpu_ctx, sc, cam, mipt.render_params(W, H, sample_count=6, max_depth=4, tile_size=32), full)
+        ref = full.read()
+        # tiles: 3 shards, each into its own film; pack -> unpack into a fourth (what all-gather does)
+        import torch
+        assembled = mipt.Film(gpu_ctx, W, H)
+        for r in range(3):
+            part = mipt.Film(gpu_ctx, W, H)
+            mipt.render(gpu_ctx, sc, cam, mipt.render_params(W, H, sample_count=6, max_depth=4, tile_size=32,
+                                                            shard_index=r, shard_count=3), part)
+            n = part.packed_size(32, r, 3)
+            buf = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+            gpu_ctx.synchronize()
+            part.pack_tiles(32, r, 3, buf.data_ptr())
+            assembled.unpack_tiles(32, r, 3, buf.data_ptr())
+            gpu_ctx.synchronize()
+            owned = part.read()[..., 3] > 0
+            assert 0 < owned.sum() < W * H
+            part.close()
+        np.testing.assert_array_equal(assembled.read().view(np.uint32), ref.view(np.uint32))
+        # samples: two ranks with 4 + 2 samples, films added
+        a, b = mipt.Film(gpu_ctx, W, H), mipt.Film(gpu_ctx, W, H)
+        mipt.render(gpu_ctx, sc, cam, mipt.render_params(W, H, sample_begin=0, sample_count=4, max_depth=4), a)
+        mipt.render(gpu_ctx, sc, cam, mipt.render_params(W, H, sample_begin=4, sample_count=2, max_depth=4), b)
+        s = a.read() + b.read()
+        assert rel_rmse(s[..., :3], ref[..., :3]) < 1e-6
+        np.testing.assert_array_equal(s[..., 3], ref[..., 3])
+        for f in (full, assembled, a, b):
+            f.close()
+    finally:
+        sc.close()
+
+
+def test_film_wrap_and_errors(mipt, scenes, gpu_ctx):
+    import torch
+    nodes, sc = _setup(mipt, gpu_ctx, scenes.fallback_quad())
+    try:
+        t = torch.zeros((8, 16, 4), dtype=torch.float32, device="cuda")
+        film = mipt.Film(gpu_ctx, 16, 8, device_ptr=t.data_ptr())
+        cam = mipt.look_at_camera((5, 0, 0), (0, 0, 0), fovy_deg=30.0)
+        mipt.render(gpu_ctx, sc, cam, mipt.render_params(16, 8, sample_count=2, background=(1, 1, 1)), film)
+        gpu_ctx.synchronize()
+        assert (t[..., 3] == 2).all().item() and t[..., :3].sum().item() > 0
+        film.clear()
+        gpu_ctx.synchronize()
+        assert t.abs().sum().item() == 0
+        with pytest.raises(mipt.MiptError, match="image size"):
+            mipt.render(gpu_ctx, sc, cam, mipt.render_params(32, 8), film)
+        with pytest.raises(mipt.MiptError, match="max_depth"):
+            mipt.render(gpu_ctx, sc, cam, mipt.render_params(16, 8, max_depth=0), film)
+        with pytest.raises(mipt.MiptError, match="tile_size"):
+            mipt.render(gpu_ctx, sc, cam, mipt.render_params(16, 8, tile_size=12), film)
+        with pytest.raises(mipt.MiptError, match="not implemented"):
+            mipt.render(gpu_ctx, sc, cam, mipt.render_params(16, 8, flags=mipt.PT_RENDER_NEE), film)
+        film.close()
+    finally:
+        sc.close()
