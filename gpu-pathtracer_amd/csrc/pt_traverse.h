@@ -278,4 +278,31 @@ __device__ __forceinline__ uint32_t queue_append(bool keep, unsigned int *count)
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// Workgroup-wide form: one atomic per workgroup instead of one per wave (a single counter
+// word sustains only ~90 returning atomics per microsecond chip-wide, which at one atomic
+// per 64 rays would cap a queue at ~6 Grays/s of appends and serialise the launch).
+// Every thread of the workgroup must call it; `scratch` is >= 17 words of LDS.
+__device__ __forceinline__ uint32_t block_queue_append(bool keep, unsigned int *count,
+                                                       unsigned int *scratch) {
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_waves = (blockDim.x + 63) >> 6;
+    if (lane == 0) scratch[wave] = (unsigned int)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int total = 0;
+        for (int w = 0; w < n_waves; ++w) {
+            const unsigned int c = scratch[w];
+            scratch[w] = total;          // exclusive prefix over the waves
+            total += c;
+        }
+        scratch[16] = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t slot = scratch[16] + scratch[wave] +
+                          (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();                     // scratch may be reused by the caller
+    return slot;
+}
+
 } // namespace mipt

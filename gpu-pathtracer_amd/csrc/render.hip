@@ -21,9 +21,12 @@ namespace {
 
 constexpr int kBlock = kTraceBlock;
 
-__global__ __launch_bounds__(256) void k_pt_raygen(RenderLaunch rl, RenderWorkspace ws,
-                                                   unsigned int *count_out) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+constexpr int kWideBlock = 1024;   // raygen / shade: 16 waves share one queue atomic
+
+__global__ __launch_bounds__(kWideBlock) void k_pt_raygen(RenderLaunch rl, RenderWorkspace ws,
+                                                          unsigned int *count_out) {
+    __shared__ unsigned int s_q[17];
+    const uint64_t i = (uint64_t)blockIdx.x * kWideBlock + threadIdx.x;
     const uint64_t total = (uint64_t)rl.n_samples * rl.map.n_local;
     bool valid = false;
     float4 o = make_float4(0, 0, 0, 0), d = make_float4(0, 0, 0, 0);
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256) void k_pt_raygen(RenderLaunch rl, RenderWorksp
         }
         ws.radiance[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const uint32_t slot = queue_append(valid, count_out);
+    const uint32_t slot = block_queue_append(valid, count_out, s_q);
     if (valid) {
         float4 *r = reinterpret_cast<float4 *>(ws.rays[0] + slot);
         r[0] = o;
@@ -86,12 +89,14 @@ __global__ __launch_bounds__(kBlock) void k_pt_extend(DeviceScene s, const pt_ra
 }
 
 // shade: one path vertex per queued hit; survivors are appended to the next queue.
-__global__ __launch_bounds__(256) void k_pt_shade(DeviceScene s, RenderLaunch rl, RenderWorkspace ws,
-                                                  int buf_in, const unsigned int *count_in,
-                                                  unsigned int *count_out, uint32_t bounce) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(kWideBlock) void k_pt_shade(DeviceScene s, RenderLaunch rl,
+                                                         RenderWorkspace ws, int buf_in,
+                                                         const unsigned int *count_in,
+                                                         unsigned int *count_out, uint32_t bounce) {
+    __shared__ unsigned int s_q[17];
+    const uint64_t i = (uint64_t)blockIdx.x * kWideBlock + threadIdx.x;
     const uint64_t n = *count_in;
-    if ((uint64_t)blockIdx.x * 256 >= n) return;
+    if ((uint64_t)blockIdx.x * kWideBlock >= n) return;
     bool alive = false;
     uint32_t pid = 0;
     V3 no = v3(0, 0, 0), nd = v3(0, 0, 0);
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void k_pt_shade(DeviceScene s, RenderLaunch rl
         }
         ws.radiance[pid] = L;
     }
-    const uint32_t slot = queue_append(alive, count_out);
+    const uint32_t slot = block_queue_append(alive, count_out, s_q);
     if (alive) {
         float4 *r = reinterpret_cast<float4 *>(ws.rays[buf_in ^ 1] + slot);
         r[0] = make_float4(no.x, no.y, no.z, 1e30f);
@@ -194,7 +199,8 @@ void launch_pt_raygen(hipStream_t st, const RenderLaunch &rl, const RenderWorksp
                       unsigned int *count_out) {
     const uint64_t total = (uint64_t)rl.n_samples * rl.map.n_local;
     if (!total) return;
-    hipLaunchKernelGGL(k_pt_raygen, dim3(blocks(total, 256)), dim3(256), 0, st, rl, ws, count_out);
+    hipLaunchKernelGGL(k_pt_raygen, dim3(blocks(total, kWideBlock)), dim3(kWideBlock), 0, st, rl, ws,
+                       count_out);
 }
 
 void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspace &ws, int buf,
@@ -213,8 +219,8 @@ void launch_pt_shade(hipStream_t st, const DeviceScene &s, const RenderLaunch &r
                      const RenderWorkspace &ws, int buf_in, const unsigned int *count_in,
                      unsigned int *count_out, uint64_t max_rays, uint32_t bounce) {
     if (!max_rays) return;
-    hipLaunchKernelGGL(k_pt_shade, dim3(blocks(max_rays, 256)), dim3(256), 0, st, s, rl, ws, buf_in,
-                       count_in, count_out, bounce);
+    hipLaunchKernelGGL(k_pt_shade, dim3(blocks(max_rays, kWideBlock)), dim3(kWideBlock), 0, st, s,
+                       rl, ws, buf_in, count_in, count_out, bounce);
 }
 
 void launch_pt_shade_depth(hipStream_t st, const RenderWorkspace &ws, const unsigned int *count,
