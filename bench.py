@@ -40,6 +40,10 @@ def parse_args():
     ap.add_argument("--tris", type=int, default=262144)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--spp-per-step", type=int, default=4)
+    ap.add_argument("--sharding", choices=["samples", "tiles"], default="samples",
+                    help="how N ranks split the frame (N > 1)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=INT",
+                    help="pt_context_set_option tuning knob, e.g. extend.persistent=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-scale", type=int, default=2,
                     help="the CPU baseline renders the frame at 1/scale resolution in x and y")
@@ -72,6 +76,9 @@ def main():
     stream = torch.cuda.Stream()          # the library's kernels and the timing share this stream
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
+    for opt in args.option:
+        key, _, val = opt.partition("=")
+        ctx.set_option(key, int(val))
     scene = mipt.Scene(ctx, nodes, vtx, idx, mats, mids)
     W, H, spp = args.width, args.height, args.spp_per_step
     cam = scenes.atrium_camera(W / H)
@@ -79,11 +86,27 @@ def main():
     film = mipt.Film(ctx, W, H, device_ptr=film_t.data_ptr())
     sky = (0.55, 0.65, 0.8)
 
+    from mipt import distributed as D
+
     def params(step, flags=0):
+        common = dict(max_depth=args.depth, seed=42, rr_start_depth=3, background=sky, flags=flags)
+        if args.sharding == "tiles":
+            # rank r renders the tiles it owns with world*spp samples: same work per rank
+            return mipt.render_params(W, H, sample_begin=step * world * spp, sample_count=world * spp,
+                                      **D.tile_shard_kwargs(rank, world, 64), **common)
         # rank r renders samples [(step*world + r)*spp, +spp) of every pixel
         return mipt.render_params(W, H, sample_begin=(step * world + rank) * spp, sample_count=spp,
-                                  max_depth=args.depth, seed=42, rr_start_depth=3, background=sky,
-                                  flags=flags)
+                                  **common)
+
+    def assemble():
+        if world == 1:
+            return
+        if args.sharding == "tiles":
+            sizes = [film.packed_size(64, r, world) for r in range(world)]
+            D.assemble_tiles(sizes, lambda r, buf: film.pack_tiles(64, r, world, buf.data_ptr()),
+                             lambda r, buf: film.unpack_tiles(64, r, world, buf.data_ptr()), "cuda")
+        else:
+            D.assemble_samples(film_t, dst=0)
 
     # ---- work per ray (untimed): the same kernels with their test counters compiled in ------
     st = mipt.render(ctx, scene, cam, params(0, mipt.PT_RENDER_COUNT_WORK), film, stats=True)
@@ -110,8 +133,7 @@ def main():
         ties += st.tie_rays
         launches += st.extend_launches
         extend_ms += st.extend_ms
-    if world > 1:
-        dist.reduce(film_t, dst=0, op=dist.ReduceOp.SUM)       # frame assembly over RCCL
+    assemble()                                                 # frame assembly over RCCL
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -145,7 +167,9 @@ def main():
                        "rays_per_step_per_gpu": rays / args.steps,
                        "samples_per_pixel_total": args.steps * spp * world,
                        "bvh_build_s": round(build_s, 3),
-                       "sharding": "sample ranges per rank, RCCL reduce of the film at the end"},
+                       "sharding": ("sample ranges per rank, RCCL reduce of the film at the end"
+                                    if args.sharding == "samples" else
+                                    "64x64 tiles round-robin over ranks, RCCL all-gather of packed tiles")},
             "nodes_per_ray": n_box, "tris_per_ray": n_tri, "bytes_per_ray": bytes_per_ray,
             "tie_rays": int(ties), "mean_radiance": float(img.mean().item()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

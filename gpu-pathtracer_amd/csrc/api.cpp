@@ -246,6 +246,7 @@ int pt_context_create(int device, pt_context **out) {
     HIP_CHECK(hipSetDevice(device));
     auto ctx = std::make_unique<pt_context>();
     ctx->device = device;
+    HIP_CHECK(hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device));
     HIP_CHECK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     HIP_CHECK(hipMalloc((void **)&ctx->counters, sizeof(DeviceTraceCounters)));
@@ -276,6 +277,26 @@ int pt_context_synchronize(pt_context *ctx) {
 int pt_context_set_kernel_timing(pt_context *ctx, int on) {
     if (!ctx) return fail(PT_ERR_INVALID, "pt_context_set_kernel_timing: null context");
     ctx->kernel_timing = on != 0;
+    return PT_OK;
+}
+
+int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
+    if (!ctx || !key || !value) return fail(PT_ERR_INVALID, "pt_context_set_option: null argument");
+    char *end = nullptr;
+    const long v = std::strtol(value, &end, 10);
+    if (end == value) return fail(PT_ERR_INVALID, std::string("option '") + key + "': not an integer");
+    const std::string k(key);
+    if (k == "extend.persistent") {
+        ctx->extend_persistent = v != 0;
+    } else if (k == "extend.refill") {
+        if (v < 1 || v > 64) return fail(PT_ERR_INVALID, "extend.refill must be in [1,64]");
+        ctx->extend_refill = (int)v;
+    } else if (k == "extend.blocks_per_cu") {
+        if (v < 1 || v > 8) return fail(PT_ERR_INVALID, "extend.blocks_per_cu must be in [1,8]");
+        ctx->extend_blocks_per_cu = (int)v;
+    } else {
+        return fail(PT_ERR_INVALID, "unknown option '" + k + "'");
+    }
     return PT_OK;
 }
 
@@ -409,7 +430,8 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
         launch_trace_skiplink(st, scene->dev, rays_dev, hits_dev, n, mt,
                               count ? ctx->counters : nullptr);
     } else {
-        launch_trace_ordered(st, scene->dev, rays_dev, hits_dev, n, fixup, ctx->counters, count);
+        launch_trace_ordered(st, scene->dev, rays_dev, hits_dev, n, fixup, ctx->counters, count,
+                             ctx->extend_config());
     }
     HIP_CHECK(hipGetLastError());
     if (stats) {

@@ -30,12 +30,25 @@ struct pt_context {
     hipStream_t stream = nullptr;
     bool external_stream = false;
     bool kernel_timing = false;
+    int num_cus = 0;
+    int extend_persistent = 1;      // option "extend.persistent"
+    int extend_refill = 16;         // option "extend.refill"
+    int extend_blocks_per_cu = 6;   // option "extend.blocks_per_cu"
     mipt::DeviceTraceCounters *counters = nullptr;
     mipt::DeviceBuffer io_rays;     // staging for the host-pointer entry points
     mipt::DeviceBuffer io_hits;
     mipt::DeviceBuffer render_ws;   // wavefront state of pt_render
     mipt::DeviceBuffer render_counts;   // queue sizes per pass and bounce
     std::vector<hipEvent_t> events;     // pool for per-kernel timing
+
+    mipt::ExtendConfig extend_config() const {
+        mipt::ExtendConfig c;
+        c.persistent_blocks = extend_persistent ? 1 : 0;
+        c.num_cus = num_cus;
+        c.blocks_per_cu = extend_blocks_per_cu;
+        c.refill = extend_refill;
+        return c;
+    }
 
     void release_all() {
         render_counts.release();

@@ -32,6 +32,14 @@ struct DeviceTraceCounters {
     unsigned int _pad;
 };
 
+// How the closest-hit kernels are launched.
+struct ExtendConfig {
+    int persistent_blocks;  // > 0: persistent waves; 0: one thread per ray
+    int num_cus;            // compute units of the device
+    int blocks_per_cu;      // persistent form: upper bound on workgroups per compute unit
+    int refill;             // persistent form: top up a wave when this many lanes are idle
+};
+
 // Closest hit in the reference's fixed skip-link order.
 void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                            uint64_t n, bool moller_trumbore, DeviceTraceCounters *counters);
@@ -41,7 +49,11 @@ void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *r
 // in the fixed order inside the same kernel.
 void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                           uint64_t n, bool fixup, DeviceTraceCounters *counters,
-                          bool count_work);
+                          bool count_work, const ExtendConfig &cfg);
+
+// Workgroups of `block` threads a persistent kernel may launch and still have them all
+// resident: compute units x min(cap, what the occupancy query admits).
+unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg, int *cache);
 
 void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, int32_t *occluded,
                       uint64_t n);

@@ -199,6 +199,107 @@ __device__ __forceinline__ void traverse_ordered(const DeviceScene &s, const flo
     if (primid >= 0 && second <= tbest + tbest * PT_TIE_WINDOW) tie = true;
 }
 
+// ---- the same traversal as a resumable state machine (persistent-wave kernels) ---------
+struct OrderedState {
+    RayPre r;
+    float tmax, tbest, bound, second, b0, b1, b2;
+    int32_t primid, cur;     // cur == kSentinel: no traversal in progress
+    int sp;
+    bool tie;
+};
+
+__device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro, const float4 rd) {
+    st.r = precompute_ray(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+    st.tmax = ro.w;
+    st.b0 = 0.f; st.b1 = 0.f; st.b2 = 0.f;
+    st.tbest = st.tmax;
+    st.bound = st.tmax;
+    st.second = INFINITY;
+    st.primid = -1;
+    st.tie = false;
+    st.sp = 0;
+    st.cur = 0;
+    const float chk = ((ro.x + ro.y) + (ro.z + rd.x)) + (rd.y + rd.z);
+    if (!(fabsf(chk) < INFINITY) || !(st.tmax == st.tmax) ||
+        (rd.x == 0.f && rd.y == 0.f && rd.z == 0.f)) {
+        st.tie = true;
+        st.cur = kSentinel;
+    }
+}
+
+// Advances every traversing lane of the wave until at most `min_active` of them are still
+// traversing (0: run the wave's rays to completion).
+template <bool COUNT>
+__device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedState &st,
+                                                int32_t *stack, int min_active,
+                                                unsigned long long &nb, unsigned long long &nt) {
+    for (;;) {
+        while (st.cur >= 0) {
+            const float4 *np = s.wnodes + 4 * (int64_t)st.cur;
+            const float4 a = np[0], b = np[1], c = np[2];
+            const int4 ch = reinterpret_cast<const int4 *>(np)[3];
+            if (COUNT) nb += 2;
+            float ta, tb;
+            const bool ha = intersect_box(st.r, a.x, a.y, a.z, a.w, c.x, c.y, st.bound, ta);
+            const bool hb = intersect_box(st.r, b.x, b.y, b.z, b.w, c.z, c.w, st.bound, tb);
+            if (ha && hb) {
+                const bool swap = tb < ta;
+                const int32_t near_c = swap ? ch.y : ch.x;
+                const int32_t far_c = swap ? ch.x : ch.y;
+                if (st.sp < kTraceStack) {
+                    stack[st.sp * kTraceBlock] = far_c;
+                    ++st.sp;
+                    st.cur = near_c;
+                } else {
+                    st.tie = true;
+                    st.cur = kSentinel;
+                }
+            } else if (ha || hb) {
+                st.cur = ha ? ch.x : ch.y;
+            } else if (st.sp > 0) {
+                --st.sp;
+                st.cur = stack[st.sp * kTraceBlock];
+            } else {
+                st.cur = kSentinel;
+            }
+        }
+        while (st.cur < 0 && st.cur != kSentinel) {
+            const float4 *tp = s.wtris + 3 * (int64_t)(~st.cur);
+            const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+            if (COUNT) ++nt;
+            float h0, h1, h2, ht;
+            if (intersect_triangle_watertight(st.r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                                              q2.x, st.bound, h0, h1, h2, ht)) {
+                if (!(ht == ht)) {
+                    st.tie = true;
+                    st.cur = kSentinel;
+                    break;
+                }
+                if (st.primid < 0 || ht < st.tbest) {
+                    if (st.primid >= 0) st.second = fminf(st.second, st.tbest);
+                    st.tbest = ht; st.b0 = h0; st.b1 = h1; st.b2 = h2;
+                    st.primid = __float_as_int(q2.y);
+                    st.bound = fminf(st.tbest + st.tbest * PT_TIE_WINDOW, st.tmax);
+                } else {
+                    st.second = fminf(st.second, ht);
+                }
+            }
+            if (st.sp > 0) {
+                --st.sp;
+                st.cur = stack[st.sp * kTraceBlock];
+            } else {
+                st.cur = kSentinel;
+            }
+        }
+        if ((int)__popcll(__ballot(st.cur != kSentinel)) <= min_active) break;
+    }
+}
+
+// Call once for a lane whose traversal has ended; true if the ray must be re-resolved.
+__device__ __forceinline__ bool ordered_is_tie(const OrderedState &st) {
+    return st.tie || (st.primid >= 0 && st.second <= st.tbest + st.tbest * PT_TIE_WINDOW);
+}
+
 // Closest hit of one ray with the reference's result.  Returns whether the fixed-order
 // traversal had to be run (or would have been, when fixup is off).
 template <bool COUNT>
@@ -262,6 +363,83 @@ __device__ __forceinline__ void count_ties(bool tie, unsigned int *tie_count) {
     const unsigned long long m = __ballot(tie);
     if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1)
         atomicAdd(tie_count, (unsigned int)__popcll(m));
+}
+
+// Closest hits of rays[0..n) by persistent waves: the grid is sized to the machine, not to
+// the queue.  Chunks of 64 rays are dealt round-robin to the waves (chunk c belongs to wave
+// c % n_waves: static, so no work-distribution atomics), and a wave tops its idle lanes up
+// from its own stream whenever `refill` or more of them have finished, instead of idling
+// them until its slowest ray ends.  Every wave reaches the end of its finite stream, so the
+// grid always drains.
+template <bool COUNT>
+__device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, const pt_ray *rays,
+                                                        pt_hit *hits, uint32_t n, bool fixup,
+                                                        int refill, int32_t *stack,
+                                                        unsigned int *tie_count,
+                                                        DeviceTraceCounters *work) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * (kTraceBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (kTraceBlock / 64);
+    const uint32_t n_chunks = (n + 63u) >> 6;
+    const uint32_t owned = wave < n_chunks ? (n_chunks - wave + n_waves - 1) / n_waves : 0;
+    const uint32_t stream_len = owned << 6;     // positions in this wave's stream
+    uint32_t pos = 0;                           // next unread position (wave-uniform)
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    uint32_t my_ray = kNone;
+    OrderedState st;
+    st.cur = kSentinel;
+    st.tie = false;
+    st.primid = -1;
+    st.second = INFINITY;
+    st.tbest = 0.f;
+    unsigned long long nb = 0, nt = 0;
+    unsigned int n_ties = 0;
+    for (;;) {
+        if (my_ray != kNone && st.cur == kSentinel) {          // retire a finished ray
+            int32_t shapeid = st.primid >= 0 ? 0 : -1, primid = st.primid;
+            float b0 = st.b0, b1 = st.b1, b2 = st.b2, t = st.tbest;
+            if (ordered_is_tie(st)) {
+                ++n_ties;
+            }
+            if (fixup && ordered_is_tie(st)) {
+                unsigned long long xb = 0, xt = 0;
+                const float4 ro = reinterpret_cast<const float4 *>(rays + my_ray)[0];
+                const float4 rd = reinterpret_cast<const float4 *>(rays + my_ray)[1];
+                traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt);
+            }
+            store_hit(hits, my_ray, shapeid, primid, b0, b1, b2, t);
+            my_ray = kNone;
+        }
+        const bool idle = my_ray == kNone;
+        const unsigned long long m = __ballot(idle);
+        if (pos < stream_len && m) {                            // top up idle lanes
+            const uint32_t p = pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (idle && p < stream_len) {
+                const uint32_t idx = (((p >> 6) * n_waves + wave) << 6) + (p & 63u);
+                if (idx < n) {
+                    const float4 ro = reinterpret_cast<const float4 *>(rays + idx)[0];
+                    const float4 rd = reinterpret_cast<const float4 *>(rays + idx)[1];
+                    ordered_begin(st, ro, rd);
+                    my_ray = idx;
+                }
+            }
+            pos += (uint32_t)__popcll(m);
+        }
+        if (__ballot(my_ray != kNone) == 0ull) {
+            if (pos >= stream_len) break;
+            continue;                                           // tail positions past the queue end
+        }
+        ordered_advance<COUNT>(s, st, stack, pos < stream_len ? 64 - refill : 0, nb, nt);
+    }
+    if (n_ties) atomicAdd(tie_count, n_ties);
+    if (COUNT) {
+        nb = wave_sum(nb);
+        nt = wave_sum(nt);
+        if (lane == 0) {
+            atomicAdd(&work->box_tests, nb);
+            atomicAdd(&work->tri_tests, nt);
+        }
+    }
 }
 
 // Compacting append to a queue: every lane with `keep` gets a distinct slot.  One atomic

@@ -58,7 +58,7 @@ void launch_pt_raygen(hipStream_t st, const RenderLaunch &rl, const RenderWorksp
                       unsigned int *count_out);
 void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspace &ws, int buf,
                       const unsigned int *count, uint64_t max_rays, unsigned int *tie_count,
-                      DeviceTraceCounters *work);
+                      DeviceTraceCounters *work, const ExtendConfig &cfg);
 void launch_pt_shade(hipStream_t st, const DeviceScene &s, const RenderLaunch &rl,
                      const RenderWorkspace &ws, int buf_in, const unsigned int *count_in,
                      unsigned int *count_out, uint64_t max_rays, uint32_t bounce);

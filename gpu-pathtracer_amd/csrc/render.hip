@@ -11,6 +11,8 @@
 // atomic per wavefront (ballot + prefix count).
 #include "render.h"
 
+#include <algorithm>
+
 #include "pt_camera_math.h"
 #include "pt_shade_math.h"
 #include "pt_traverse.h"
@@ -20,6 +22,12 @@ namespace mipt {
 namespace {
 
 constexpr int kBlock = kTraceBlock;
+
+// Minimum resident waves per SIMD the closest-hit kernels are compiled for (second
+// argument of __launch_bounds__): bounds their VGPR allocation.
+#ifndef PT_EXTEND_MIN_WAVES
+#define PT_EXTEND_MIN_WAVES 1
+#endif
 
 constexpr int kWideBlock = 1024;   // raygen / shade: 16 waves share one queue atomic
 
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(kWideBlock) void k_pt_raygen(RenderLaunch rl, Rende
 
 // extend: closest hit of every queued ray.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_pt_extend(DeviceScene s, const pt_ray *rays,
+__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend(DeviceScene s, const pt_ray *rays,
                                                      pt_hit *hits, const unsigned int *count,
                                                      unsigned int *tie_count,
                                                      DeviceTraceCounters *work) {
@@ -86,6 +94,23 @@ __global__ __launch_bounds__(kBlock) void k_pt_extend(DeviceScene s, const pt_ra
             atomicAdd(&work->tri_tests, nt);
         }
     }
+}
+
+// extend, persistent form: the grid is sized to the machine, not to the queue.  Queue
+// chunks of 64 rays are dealt round-robin to the waves (chunk c belongs to wave c % n_waves:
+// static, so no work-distribution atomics), and a wave tops its idle lanes up from its own
+// stream whenever `refill` or more of them have finished, instead of idling them until its
+// slowest ray ends.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_persistent(DeviceScene s, const pt_ray *rays,
+                                                                pt_hit *hits,
+                                                                const unsigned int *count,
+                                                                unsigned int *tie_count,
+                                                                DeviceTraceCounters *work,
+                                                                int refill) {
+    __shared__ int32_t s_stack[kTraceStack * kBlock];
+    persistent_closest_hits<COUNT>(s, rays, hits, *count, true, refill, s_stack + threadIdx.x,
+                                   tie_count, work);
 }
 
 // shade: one path vertex per queued hit; survivors are appended to the next queue.
@@ -205,8 +230,22 @@ void launch_pt_raygen(hipStream_t st, const RenderLaunch &rl, const RenderWorksp
 
 void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspace &ws, int buf,
                       const unsigned int *count, uint64_t max_rays, unsigned int *tie_count,
-                      DeviceTraceCounters *work) {
+                      DeviceTraceCounters *work, const ExtendConfig &cfg) {
     if (!max_rays) return;
+    if (cfg.persistent_blocks > 0) {
+        static int occ[2] = {0, 0};
+        const void *k = work ? (const void *)k_pt_extend_persistent<true>
+                             : (const void *)k_pt_extend_persistent<false>;
+        const unsigned int grid = (unsigned int)std::min<uint64_t>(
+            blocks(max_rays, kBlock), persistent_grid(k, kBlock, cfg, &occ[work ? 1 : 0]));
+        if (work)
+            hipLaunchKernelGGL(k_pt_extend_persistent<true>, dim3(grid), dim3(kBlock), 0, st, s,
+                               ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill);
+        else
+            hipLaunchKernelGGL(k_pt_extend_persistent<false>, dim3(grid), dim3(kBlock), 0, st, s,
+                               ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill);
+        return;
+    }
     if (work)
         hipLaunchKernelGGL(k_pt_extend<true>, dim3(blocks(max_rays, kBlock)), dim3(kBlock), 0, st,
                            s, ws.rays[buf], ws.hits, count, tie_count, work);

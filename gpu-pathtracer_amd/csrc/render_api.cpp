@@ -137,6 +137,24 @@ int pt_film_destroy(pt_film *film) {
     return PT_OK;
 }
 
+int pt_shard_layout(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t shard_index,
+                    uint32_t shard_count, uint64_t *n_slots, int32_t *xy) {
+    if (!n_slots) return fail(PT_ERR_INVALID, "pt_shard_layout: null argument");
+    PixelMap m;
+    int rc = make_pixel_map(width, height, tile_size, shard_index, shard_count, m);
+    if (rc != PT_OK) return rc;
+    *n_slots = m.n_local;
+    if (xy) {
+        for (uint32_t lp = 0; lp < m.n_local; ++lp) {
+            uint32_t x, y;
+            const bool ok = local_to_pixel(m, lp, x, y);
+            xy[2 * (size_t)lp + 0] = ok ? (int32_t)x : -1;
+            xy[2 * (size_t)lp + 1] = ok ? (int32_t)y : -1;
+        }
+    }
+    return PT_OK;
+}
+
 uint64_t pt_film_packed_size(const pt_film *film, uint32_t tile_size, uint32_t shard_index,
                              uint32_t shard_count) {
     if (!film) return 0;
@@ -252,6 +270,7 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
         work = ctx->counters;
         HIP_CHECK(hipMemsetAsync(work, 0, sizeof(DeviceTraceCounters), st));
     }
+    const ExtendConfig ecfg = ctx->extend_config();
     const bool timing = ctx->kernel_timing;
     size_t n_events = 0;
     if (timing) {
@@ -272,7 +291,7 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
         int buf = 0;
         for (uint32_t b = 0; b < p.max_depth; ++b) {
             if (timing) HIP_CHECK(hipEventRecord(ctx->events[n_events++], st));
-            launch_pt_extend(st, scene->dev, ws, buf, &c[b], paths, tie_count, work);
+            launch_pt_extend(st, scene->dev, ws, buf, &c[b], paths, tie_count, work, ecfg);
             if (timing) HIP_CHECK(hipEventRecord(ctx->events[n_events++], st));
             if (depth_mode) {
                 launch_pt_shade_depth(st, ws, &c[b], paths);

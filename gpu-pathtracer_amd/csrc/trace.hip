@@ -62,6 +62,17 @@ __global__ __launch_bounds__(kBlock) void k_trace_ordered(DeviceScene s, const p
     }
 }
 
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_ordered_persistent(DeviceScene s,
+                                                                    const pt_ray *rays,
+                                                                    pt_hit *hits, uint32_t n,
+                                                                    bool fixup, int refill,
+                                                                    DeviceTraceCounters *counters) {
+    __shared__ int32_t s_stack[kTraceStack * kBlock];
+    persistent_closest_hits<COUNT>(s, rays, hits, n, fixup, refill, s_stack + threadIdx.x,
+                                   &counters->tie_count, counters);
+}
+
 // IntersectSceneAny, shaders/RadeonRays/bvh.glslh:378-414 (leaf test :350-375, :289-310).
 __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene s, const pt_ray *rays,
                                                      int32_t *occluded, uint64_t n) {
@@ -75,6 +86,17 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene s, const pt_ra
 inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kBlock - 1) / kBlock); }
 
 } // namespace
+
+unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg, int *cache) {
+    // Never launch more persistent workgroups than can be resident at once: the surplus
+    // would only start after the first ones have finished their whole streams.
+    if (*cache == 0) {
+        int nb = 0;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0);
+        *cache = (e == hipSuccess && nb > 0) ? nb : 4;
+    }
+    return (unsigned int)(cfg.num_cus * std::min(*cache, cfg.blocks_per_cu));
+}
 
 void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                            uint64_t n, bool moller_trumbore, DeviceTraceCounters *counters) {
@@ -100,8 +122,22 @@ void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *r
 
 void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                           uint64_t n, bool fixup, DeviceTraceCounters *counters,
-                          bool count_work) {
+                          bool count_work, const ExtendConfig &cfg) {
     if (n == 0) return;
+    if (cfg.persistent_blocks > 0) {
+        static int occ[2] = {0, 0};
+        const void *k = count_work ? (const void *)k_trace_ordered_persistent<true>
+                                   : (const void *)k_trace_ordered_persistent<false>;
+        const unsigned int grid = (unsigned int)std::min<uint64_t>(
+            grid_for(n), persistent_grid(k, kBlock, cfg, &occ[count_work ? 1 : 0]));
+        if (count_work)
+            hipLaunchKernelGGL((k_trace_ordered_persistent<true>), dim3(grid), dim3(kBlock), 0, st,
+                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, counters);
+        else
+            hipLaunchKernelGGL((k_trace_ordered_persistent<false>), dim3(grid), dim3(kBlock), 0, st,
+                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, counters);
+        return;
+    }
     const unsigned int grid = grid_for(n);
     if (count_work)
         hipLaunchKernelGGL((k_trace_ordered<true>), dim3(grid), dim3(kBlock), 0, st, s, rays, hits,

@@ -192,14 +192,22 @@ void build_wide_layout(const BvhTree &t, const float *vtx, uint32_t n_vtx, const
     };
 
     if (n == 1) {
-        // Single triangle: a root whose second child can never be hit.
+        // Single triangle: the root's second child is a record whose three vertices
+        // coincide.  Its edge functions are exactly zero for every finite ray, so the
+        // triangle test rejects it (det == 0) and it can never become a candidate.  (An
+        // "inverted" box would not do: the slab test takes min/max of the two planes, so a
+        // box with min > max looks unbounded, not empty.)
         WideNode &w = out.nodes[0];
         set_child(w, 0, 0);
-        w.c1xy[0] = w.c1xy[2] = w.cz[2] = INFINITY;
-        w.c1xy[1] = w.c1xy[3] = w.cz[3] = -INFINITY;
-        w.child[1] = ~0;
+        set_child(w, 1, 0);
+        w.child[1] = ~1;
         w.child[2] = w.child[3] = 0;
+        out.tris.assign(2, TriRecord{});
         fill_tri(0);
+        TriRecord &r = out.tris[1];
+        r = out.tris[0];
+        r.v1x = r.v0[0]; r.v1yz[0] = r.v0[1]; r.v1yz[1] = r.v0[2];
+        r.v2xy[0] = r.v0[0]; r.v2xy[1] = r.v0[1]; r.v2z = r.v0[2];
         return;
     }
     for (size_t i = 0; i < n; ++i) {

@@ -15,7 +15,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmipt.so")
+LIB_PATH = os.environ.get("MIPT_LIB") or os.path.join(os.path.dirname(_HERE), "libmipt.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -117,6 +117,7 @@ _PROTOS = {
     "pt_context_stream": (_vp, [_vp]),
     "pt_context_synchronize": (C.c_int, [_vp]),
     "pt_context_set_kernel_timing": (C.c_int, [_vp, C.c_int]),
+    "pt_context_set_option": (C.c_int, [_vp, C.c_char_p, C.c_char_p]),
     "pt_context_destroy": (C.c_int, [_vp]),
     "pt_scene_create": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp,
                                   C.c_uint32, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
@@ -137,6 +138,8 @@ _PROTOS = {
     "pt_film_device_ptr": (_vp, [_vp]),
     "pt_film_read": (C.c_int, [_vp, _vp]),
     "pt_film_destroy": (C.c_int, [_vp]),
+    "pt_shard_layout": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.POINTER(C.c_uint64), _vp]),
     "pt_film_packed_size": (C.c_uint64, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "pt_film_pack_tiles": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "pt_film_unpack_tiles": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
@@ -262,6 +265,9 @@ class Context:
     def synchronize(self) -> None:
         _check(lib.pt_context_synchronize(self._h))
 
+    def set_option(self, key: str, value) -> None:
+        _check(lib.pt_context_set_option(self._h, key.encode(), str(int(value)).encode()))
+
     def set_kernel_timing(self, on: bool) -> None:
         _check(lib.pt_context_set_kernel_timing(self._h, int(on)))
 
@@ -349,6 +355,16 @@ class Scene:
 
     def trace_any_device(self, rays_dev: int, n: int, out_dev: int) -> None:
         _check(lib.pt_trace_any_device(self.ctx._h, self._h, rays_dev, n, out_dev))
+
+
+def shard_layout(width: int, height: int, tile_size: int, shard_index: int, shard_count: int):
+    """Pixel (x, y) of every slot of a shard's packed tile buffer, (-1, -1) outside the image."""
+    n = C.c_uint64()
+    _check(lib.pt_shard_layout(width, height, tile_size, shard_index, shard_count, C.byref(n), None))
+    xy = np.empty((n.value, 2), dtype=np.int32)
+    _check(lib.pt_shard_layout(width, height, tile_size, shard_index, shard_count, C.byref(n),
+                               _ptr(xy)))
+    return xy
 
 
 def render_params(width: int, height: int, **kw) -> RenderParams:

@@ -170,6 +170,12 @@ int pt_context_synchronize(pt_context *ctx);
 /* When on, every closest-hit kernel launch of pt_render is bracketed by HIP events on the
  * context's stream and summed into pt_render_stats.extend_ms. */
 int pt_context_set_kernel_timing(pt_context *ctx, int on);
+/* Tuning knobs (integers as strings).  "extend.persistent" 1|0: closest-hit kernel of
+ * pt_render as persistent waves that refill idle lanes (default 1) or one thread per ray;
+ * "extend.refill" 1..64: idle lanes that trigger a refill (default 16);
+ * "extend.blocks_per_cu" 1..8: persistent workgroups per compute unit (default 6).
+ * Results do not depend on any of them. */
+int pt_context_set_option(pt_context *ctx, const char *key, const char *value);
 int pt_context_destroy(pt_context *ctx);
 
 /* init_device_data, src/main_granite.cpp:180-194: uploads the three storage buffers the
@@ -228,6 +234,12 @@ float *pt_film_device_ptr(pt_film *film);
 /* readback_ssbo, src/main_granite.cpp:499-522: blocking copy to host memory. */
 int pt_film_read(pt_film *film, float *rgba);
 int pt_film_destroy(pt_film *film);
+
+/* Host-only description of a tile sharding: *n_slots = pixel slots of the shard (owned tiles
+ * x tile_size^2, the length of its packed buffer); if xy != NULL it receives, per slot, the
+ * pixel's x and y, or (-1,-1) for a slot outside the image.  Needs no GPU. */
+int pt_shard_layout(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t shard_index,
+                    uint32_t shard_count, uint64_t *n_slots, int32_t *xy);
 
 /* Number of float4 entries pt_film_pack_tiles writes for this sharding: tiles owned by
  * shard_index (tile t belongs to shard t % shard_count) times tile_size^2. */

@@ -22,7 +22,9 @@
  * reference's fixed skip-link order.  2^-18. */
 #define PT_TIE_WINDOW 3.814697265625e-06f
 /* Per-lane entries of the LDS traversal stack. */
+#ifndef PT_LDS_STACK_ENTRIES
 #define PT_LDS_STACK_ENTRIES 24
+#endif
 /* Threads per workgroup of the traversal kernels (4 wave64). */
 #define PT_TRACE_BLOCK 256
 

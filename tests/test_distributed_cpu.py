@@ -1,0 +1,124 @@
+"""The N>1 path on the CPU: two gloo ranks shard a frame by tiles and by sample ranges with
+the product's own sharding rules (pt_shard_layout, mipt.distributed) and assemble it; the
+pixels themselves come from the CPU oracle, since there is no GPU here.  The assembled frame
+must equal the single-rank frame (bit-exact for tiles, to rounding for sample ranges)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, TS, SPP, DEPTH = 72, 40, 16, 5, 4
+
+
+def _scene_and_camera():
+    import mipt
+    from mipt import scenes
+    from oracle import oracle
+    vtx, idx, mats, mids = scenes.cornell_box()
+    nodes = oracle.build_bvh(oracle.mesh_leaf_bounds(vtx, idx))
+    cam = mipt.look_at_camera((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), fovy_deg=39.3, aspect=W / H)
+    return mipt, oracle, (nodes, vtx, idx, mats, mids), cam
+
+
+def _render_shard(mipt, oracle, scene, cam, **kw):
+    """What pt_render does for one shard, with the oracle producing the pixels."""
+    nodes, vtx, idx, mats, mids = scene
+    p = mipt.render_params(W, H, max_depth=DEPTH, seed=3, **kw)
+    film = np.zeros((H, W, 4), dtype=np.float32)
+    xy = mipt.shard_layout(W, H, p.tile_size, p.shard_index, p.shard_count)
+    per_tile = p.tile_size * p.tile_size
+    for k in range(xy.shape[0] // per_tile):
+        t = xy[k * per_tile:(k + 1) * per_tile]
+        t = t[t[:, 0] >= 0]
+        if len(t):
+            rect = (int(t[:, 0].min()), int(t[:, 1].min()), int(t[:, 0].max()) + 1, int(t[:, 1].max()) + 1)
+            oracle.render(nodes, vtx, idx, mats, mids, cam, p, film=film, rect=rect)
+    return film, xy
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (os.path.join(REPO, "gpu-pathtracer_amd"), REPO):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mipt, oracle, scene, cam = _scene_and_camera()
+        from mipt import distributed as D
+
+        # ---- tiles -----------------------------------------------------------------------
+        film, _ = _render_shard(mipt, oracle, scene, cam, sample_count=SPP, **D.tile_shard_kwargs(rank, world, TS))
+        layouts = [mipt.shard_layout(W, H, TS, r, world) for r in range(world)]
+        ft = torch.from_numpy(film)
+
+        def pack(r, buf):
+            xy = layouts[r]
+            ok = xy[:, 0] >= 0
+            buf.zero_()
+            buf[torch.from_numpy(ok)] = ft[xy[ok, 1], xy[ok, 0]]
+
+        def unpack(r, buf):
+            xy = layouts[r]
+            ok = xy[:, 0] >= 0
+            ft[xy[ok, 1], xy[ok, 0]] = buf[torch.from_numpy(ok)]
+
+        D.assemble_tiles([len(l) for l in layouts], pack, unpack, device="cpu")
+        np.save(os.path.join(out_dir, f"tiles_{rank}.npy"), ft.numpy())
+
+        # ---- sample ranges ------------------------------------------------------------------
+        kw = D.sample_shard_kwargs(rank, world, SPP)
+        film, _ = _render_shard(mipt, oracle, scene, cam, tile_size=TS, **kw)
+        fs = torch.from_numpy(film)
+        D.assemble_samples(fs, dst=None)
+        np.save(os.path.join(out_dir, f"samples_{rank}.npy"), fs.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_assemble_one_frame(tmp_path):
+    world, port = 2, 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for p in (os.path.join(REPO, "gpu-pathtracer_amd"), REPO):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    mipt, oracle, scene, cam = _scene_and_camera()
+    full, _ = _render_shard(mipt, oracle, scene, cam, sample_count=SPP, tile_size=TS)
+    assert (full[..., 3] == SPP).all()
+    for r in range(world):
+        tiles = np.load(tmp_path / f"tiles_{r}.npy")
+        np.testing.assert_array_equal(tiles.view(np.uint32), full.view(np.uint32))
+        samples = np.load(tmp_path / f"samples_{r}.npy")
+        np.testing.assert_array_equal(samples[..., 3], full[..., 3])
+        np.testing.assert_allclose(samples[..., :3], full[..., :3], rtol=2e-6, atol=1e-7)
+
+
+def test_shard_layout_partitions_the_image():
+    for p in (os.path.join(REPO, "gpu-pathtracer_amd"), REPO):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import mipt
+    from mipt import distributed as D
+    for (w, h, ts, world) in [(72, 40, 16, 2), (100, 76, 32, 3), (1920, 1080, 64, 8), (8, 8, 64, 4)]:
+        seen = np.zeros((h, w), dtype=np.int32)
+        for r in range(world):
+            xy = mipt.shard_layout(w, h, ts, r, world)
+            assert xy.shape[0] % (ts * ts) == 0
+            ok = xy[:, 0] >= 0
+            np.add.at(seen, (xy[ok, 1], xy[ok, 0]), 1)
+            # consecutive groups of 64 slots are 8x8 pixel blocks (one wavefront's camera rays)
+            if ok.all() and len(xy):
+                blk = xy[:64]
+                assert blk[:, 0].max() - blk[:, 0].min() == 7 and blk[:, 1].max() - blk[:, 1].min() == 7
+        assert (seen == 1).all(), "tiles must cover every pixel exactly once"
+    parts = [D.sample_shard_kwargs(r, 3, 10) for r in range(3)]
+    assert [p["sample_count"] for p in parts] == [4, 3, 3]
+    assert [p["sample_begin"] for p in parts] == [0, 4, 7]
+    with pytest.raises(mipt.MiptError):
+        mipt.shard_layout(64, 64, 12, 0, 1)
+    with pytest.raises(mipt.MiptError):
+        mipt.shard_layout(64, 64, 16, 2, 2)

@@ -65,6 +65,8 @@ def test_random_soup(mipt, oracle, scenes, gpu_ctx, n_tri, seed, builder):
     nodes = _build(mipt, vtx, idx, builder)
     rays = random_rays(100000, seed + 50, dtype=mipt.ray_dtype)
     got, st = _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays)
+    if n_tri == 1:
+        assert st.tie_rays == 0          # the single-triangle root must not fake a second candidate
     if n_tri >= 1000:
         assert (got["primid"] >= 0).mean() > 0.1
         # random geometry: near ties are rare
