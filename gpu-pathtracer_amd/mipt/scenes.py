@@ -295,7 +295,7 @@ def clutter(n_tri: int, seed: int = 11):
                  ((S / 2, 0, S / 2), (-S, 0, 0)), ((S / 2, 0, -S / 2), (0, 0, S))):
         mb.grid(a, b, (0, 12, 0), shell_res, shell_res // 2, 0)
     mb.grid((-6, 11.9, -6), (12, 0, 0), (0, 0, 12), 4, 4, 3)
-    n_blobs = max(8, n_tri // 4096)
+    n_blobs = min(max(8, n_tri // 4096), 240)      # more triangles = finer blobs, not a denser cloud
     per = max(64, (n_tri - mb.n_tri) // n_blobs)
     n_lat = max(4, int(round((per / 4.0) ** 0.5)))
     for k in range(n_blobs):

@@ -113,10 +113,18 @@ def linearize(bounds, left, right, prim) -> np.ndarray:
     return out
 
 
-def closest(nodes, vtx, idx, rays, nthreads=1, counters=False, moller_trumbore=False):
+def closest(nodes, vtx, idx, rays, nthreads=1, counters=False, moller_trumbore=False,
+            int_bits=False):
     nodes, vtx, idx, rays = (_c(nodes, bbox_dtype), _c(vtx, np.float32), _c(idx, np.int32),
                              _c(rays, ray_dtype))
     out = np.zeros(rays.shape[0], dtype=isect_dtype)
+    if int_bits:
+        fn = lib().o_closest_intbits_batch
+        fn.restype = None
+        fn.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_int]
+        fn(nodes.ctypes.data, vtx.ctypes.data, idx.ctypes.data, rays.ctypes.data, rays.shape[0],
+           out.ctypes.data, nthreads)
+        return out
     if moller_trumbore:
         lib().o_closest_mt_batch(nodes.ctypes.data, vtx.ctypes.data, idx.ctypes.data,
                                  rays.ctypes.data, rays.shape[0], out.ctypes.data, nthreads)

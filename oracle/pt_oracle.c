@@ -703,3 +703,54 @@ void o_depth_shade_batch(const o_isect *isects, uint64_t n, float *rgba)
 {
     for (uint64_t i = 0; i < n; ++i) o_depth_shade(&isects[i], rgba + 4 * i);
 }
+
+/* ---------------------------------------------------------------------- */
+/* IntersectSceneClosest over nodes whose pmin.w / pmax.w hold int32 bit patterns
+ * (leaf payload or 0xFFFFFFFF; next-node index or 0xFFFFFFFF): the format documented at
+ * src/bvh/bvh_builder.h:29-33 and left as TODOs in plain_bvh_translator.cpp:58,63,66.
+ * The reference itself only emits and reads float-valued fields, which stop being exact
+ * at 2^24 nodes; this variant exists so that scenes beyond that size have a checker.  The
+ * loop is the one of shaders/RadeonRays/bvh.glslh:417-456 with the two decodes swapped. */
+static inline int32_t bits_of(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+
+static void intersect_scene_closest_intbits(const o_bbox *nodes, const float *vertices,
+                                            const int32_t *indices, const o_ray *r, o_isect *isect)
+{
+    o_ray_internal ri;
+    o_precompute_ray(r, &ri);
+    const float invdir[3] = { 1.0f / r->d[0], 1.0f / r->d[1], 1.0f / r->d[2] };
+    isect->uvwt[0] = 0.0f; isect->uvwt[1] = 0.0f; isect->uvwt[2] = 0.0f; isect->uvwt[3] = r->o[3];
+    isect->shapeid = -1; isect->primid = -1; isect->pad0 = 667; isect->pad1 = 0;
+    int32_t idx = 0;
+    while (idx != -1) {
+        const o_bbox *node = &nodes[idx];
+        if (o_intersect_box(&ri.ray, invdir, node, isect->uvwt[3])) {
+            const int32_t payload = bits_of(node->pmin[3]);
+            if (payload != -1) {
+                const int64_t start = payload;
+                float v1[3], v2[3], v3[3];
+                get_vertex(vertices, indices[3 * start + 0], v1);
+                get_vertex(vertices, indices[3 * start + 1], v2);
+                get_vertex(vertices, indices[3 * start + 2], v3);
+                if (o_intersect_triangle_watertight(&ri, v1, v2, v3, isect)) {
+                    isect->primid = payload;
+                    isect->shapeid = 0;
+                }
+                idx = bits_of(node->pmax[3]);
+            } else {
+                ++idx;
+            }
+        } else {
+            idx = bits_of(node->pmax[3]);
+        }
+    }
+}
+
+void o_closest_intbits_batch(const o_bbox *nodes, const float *vertices, const int32_t *indices,
+                             const o_ray *rays, uint64_t n, o_isect *out, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads)
+    for (int64_t i = 0; i < (int64_t)n; ++i)
+        intersect_scene_closest_intbits(nodes, vertices, indices, &rays[i], &out[i]);
+}

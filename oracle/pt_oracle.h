@@ -75,6 +75,11 @@ void o_any_batch(const o_bbox *nodes, const float *vertices, const int32_t *indi
  * shaders/RadeonRays/bvh.glslh:339. */
 void o_closest_mt_batch(const o_bbox *nodes, const float *vertices, const int32_t *indices,
                         const o_ray *rays, uint64_t n, o_isect *out, int nthreads);
+/* IntersectSceneClosest over nodes in the integer-bit-pattern encoding documented at
+ * src/bvh/bvh_builder.h:29-33 (the reference's shader only reads float-valued fields, exact
+ * below 2^24 nodes; this is the checker for larger scenes). */
+void o_closest_intbits_batch(const o_bbox *nodes, const float *vertices, const int32_t *indices,
+                             const o_ray *rays, uint64_t n, o_isect *out, int nthreads);
 /* Linear scan over every triangle in index order, same triangle test and the
  * same running tMax (pattern: shaders/depth.frag:110-129). */
 void o_brute_closest_batch(const float *vertices, const int32_t *indices, uint32_t n_tri,

@@ -1,0 +1,97 @@
+"""Full-size configurations of the baseline, checked through the oracle on samples and
+through size-independent properties on everything.
+
+* config 4: San-Miguel-class scene (9.3 M triangles, 18.5 M nodes > 2^24, so the reference's
+  float-valued links cannot express it), 3840x2160, one of 8 tile shards, primary + 1 bounce.
+* config 2: Cornell box 1920x1080, 64 spp, depth 4, Lambertian: the whole frame on the GPU,
+  a random subset of pixels recomputed by the CPU restatement.
+"""
+import numpy as np
+import pytest
+
+from conftest import same_hits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big_scene(mipt, scenes):
+    vtx, idx, mats, mids = scenes.clutter(9_000_000, seed=11)
+    lb = mipt.mesh_leaf_bounds(vtx, idx)
+    with pytest.raises(mipt.MiptError, match="2\\^24"):
+        mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": "sah"}))    # float links cannot index it
+    nodes = mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": "sah", "mipt.link_encoding": "int"}))
+    assert nodes.shape[0] == 2 * idx.shape[0] - 1 > 2 ** 24
+    return vtx, idx, mats, mids, nodes
+
+
+def test_san_miguel_class_4k_tile_shard(mipt, oracle, scenes, gpu_ctx, big_scene):
+    vtx, idx, mats, mids, nodes = big_scene
+    W, H, TS, WORLD, RANK = 3840, 2160, 64, 8, 3
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx, mats, mids, link_encoding=mipt.PT_LINKS_INT_BITS)
+    try:
+        cam = mipt.look_at_camera((-17.0, 10.5, -16.0), (3.0, 1.0, 2.0), fovy_deg=50.0, aspect=W / H)   # above the blob layer
+        # -- closest hits of this shard's camera rays plus incoherent surface rays
+        xy = mipt.shard_layout(W, H, TS, RANK, WORLD)
+        xy = xy[xy[:, 0] >= 0]
+        all_rays = gpu_ctx.raygen(cam, W, H)
+        rays = np.concatenate([all_rays[xy[:, 1].astype(np.int64) * W + xy[:, 0]],
+                               scenes.surface_rays(vtx, idx, 200_000, seed=7).astype(mipt.ray_dtype)])
+        del all_rays
+        got, st = sc.trace_closest(rays, stats=True)
+        exact = sc.trace_closest(rays, mipt.PT_TRACE_EXACT_ORDER)
+        assert len(same_hits(got, exact)) == 0            # two traversal orders, one answer
+        pick = np.random.default_rng(0).choice(len(rays), 150_000, replace=False)
+        want = oracle.closest(nodes, vtx, idx, rays[pick], nthreads=16, int_bits=True)
+        assert len(same_hits(got[pick], want)) == 0       # and it is the oracle's
+        assert (got["primid"] >= 0).mean() > 0.9
+        assert got["primid"].max() > 2 ** 23              # leaves beyond the float-exact range are hit
+        print(f"9.3M tris: {st.box_tests / len(rays):.1f} box + {st.tri_tests / len(rays):.1f} tri "
+              f"tests per ray, {st.tie_rays} ties of {len(rays)}")
+        # -- the shard's part of the frame, primary + 1 bounce
+        film = mipt.Film(gpu_ctx, W, H)
+        p = mipt.render_params(W, H, sample_count=1, max_depth=2, seed=5, tile_size=TS,
+                               shard_index=RANK, shard_count=WORLD, background=(0.5, 0.6, 0.8))
+        rs = mipt.render(gpu_ctx, sc, cam, p, film, stats=True)
+        img = film.read()
+        owned = np.zeros((H, W), dtype=bool)
+        owned[xy[:, 1], xy[:, 0]] = True
+        assert (img[..., 3] == owned).all()               # exactly the owned tiles got one sample
+        assert np.isfinite(img).all() and img[owned][:, :3].mean() > 0
+        assert rs.rays_primary == owned.sum() and 0 < rs.rays_bounce <= rs.rays_primary
+        # rendering the same samples again doubles the sums exactly (no hidden state)
+        mipt.render(gpu_ctx, sc, cam, p, film)
+        np.testing.assert_array_equal(film.read(), 2 * img)
+        film.close()
+    finally:
+        sc.close()
+
+
+def test_cornell_1080p_64spp_depth4_full_size(mipt, oracle, scenes, gpu_ctx):
+    vtx, idx, mats, mids = scenes.cornell_box()
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+    W, H = 1920, 1080
+    cam = mipt.look_at_camera((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), fovy_deg=39.3, aspect=W / H)
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx, mats, mids)
+    film = mipt.Film(gpu_ctx, W, H)
+    try:
+        p = mipt.render_params(W, H, sample_count=64, max_depth=4, seed=1)
+        st = mipt.render(gpu_ctx, sc, cam, p, film, stats=True)
+        img = film.read()
+        assert (img[..., 3] == 64).all() and np.isfinite(img).all()
+        assert st.paths == W * H * 64
+        rng = np.random.default_rng(1)
+        ref = np.zeros_like(img)
+        px = np.stack([rng.integers(0, W, 600), rng.integers(0, H, 600)], 1)
+        for x, y in np.unique(px, axis=0):
+            oracle.render(nodes, vtx, idx, mats, mids, cam, p, film=ref, rect=(x, y, x + 1, y + 1))
+        sel = ref[..., 3] > 0
+        assert sel.sum() >= 590
+        err = np.sqrt(np.mean((img[sel][:, :3] - ref[sel][:, :3]) ** 2)) / np.sqrt(np.mean(ref[sel][:, :3] ** 2))
+        assert err <= 1e-3                                 # the stated tolerance
+        np.testing.assert_array_equal(img[sel].view(np.uint32), ref[sel].view(np.uint32))   # measured: exact
+        print(f"cornell 1080p 64spp: {st.rays_primary + st.rays_bounce} rays, {st.tie_rays} ties, "
+              f"{sel.sum()} pixels recomputed on the CPU bit-identical")
+    finally:
+        film.close()
+        sc.close()

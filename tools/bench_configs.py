@@ -1,0 +1,131 @@
+"""Runs the other BASELINE.json configurations at full size on one GPU and prints one JSON
+line each (bench.py covers configs[2], the headline).  Not part of the driver contract; the
+numbers go into BASELINE.md / DESIGN.md.
+
+    python tools/bench_configs.py [cornell256 cornell1080 sanmiguel lucy]
+"""
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (os.path.join(REPO, "gpu-pathtracer_amd"), REPO):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import mipt  # noqa: E402
+from mipt import scenes  # noqa: E402
+
+
+def build(vtx, idx, enc="float"):
+    t0 = time.time()
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx),
+                           mipt.bvh_options(**{"bvh.builder": "sah", "mipt.link_encoding": enc}))
+    return nodes, time.time() - t0
+
+
+def timed(fn, ctx, reps):
+    fn()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def cornell256(ctx):
+    from oracle import oracle
+    vtx, idx, mats, mids = scenes.cornell_box()
+    nodes, bs = build(vtx, idx)
+    cam = mipt.look_at_camera((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), fovy_deg=39.3)
+    rays = ctx.raygen(cam, 256, 256)
+    t0 = time.perf_counter()
+    want = oracle.closest(nodes, vtx, idx, rays, nthreads=1)
+    cpu1 = time.perf_counter() - t0
+    sc = mipt.Scene(ctx, nodes, vtx, idx)
+    got = sc.trace_closest(rays)
+    same = bool((got["primid"] == want["primid"]).all() and
+                (got["uvwt"].view(np.uint32) == want["uvwt"].view(np.uint32)).all())
+    d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
+    d_h = torch.empty_like(d_r)
+    dt = timed(lambda: sc.trace_closest_device(d_r.data_ptr(), len(rays), d_h.data_ptr()), ctx, 50)
+    return {"config": "Cornell 256x256 1 spp primary hits", "tris": int(idx.shape[0]),
+            "bit_exact_vs_oracle": same, "cpu_1core_mrays_s": len(rays) / cpu1 / 1e6,
+            "gpu_mrays_s": len(rays) / dt / 1e6, "bvh_build_s": bs}
+
+
+def cornell1080(ctx):
+    vtx, idx, mats, mids = scenes.cornell_box()
+    nodes, bs = build(vtx, idx)
+    W, H = 1920, 1080
+    cam = mipt.look_at_camera((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), fovy_deg=39.3, aspect=W / H)
+    sc = mipt.Scene(ctx, nodes, vtx, idx, mats, mids)
+    film = mipt.Film(ctx, W, H)
+    p = mipt.render_params(W, H, sample_count=64, max_depth=4, seed=1)
+    mipt.render(ctx, sc, cam, p, film, stats=True)
+    film.clear()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    st = mipt.render(ctx, sc, cam, p, film, stats=True)
+    dt = time.perf_counter() - t0
+    rays = st.rays_primary + st.rays_bounce
+    return {"config": "Cornell 1920x1080 64 spp depth 4 Lambert", "frame_s": dt, "rays": rays,
+            "mrays_s": rays / dt / 1e6, "msamples_s": st.paths / dt / 1e6, "ties": st.tie_rays}
+
+
+def sanmiguel(ctx):
+    vtx, idx, mats, mids = scenes.clutter(10_000_000, seed=11)
+    nodes, bs = build(vtx, idx, "int")
+    W, H = 3840, 2160
+    cam = mipt.look_at_camera((-17.0, 10.5, -16.0), (3.0, 1.0, 2.0), fovy_deg=50.0, aspect=W / H)
+    sc = mipt.Scene(ctx, nodes, vtx, idx, mats, mids, link_encoding=mipt.PT_LINKS_INT_BITS)
+    film = mipt.Film(ctx, W, H)
+    out = {"config": "San-Miguel-class stand-in 3840x2160, primary + 1 bounce", "tris": int(idx.shape[0]),
+           "nodes": int(nodes.shape[0]), "bvh_build_s": bs}
+    for world in (1, 8):
+        p = mipt.render_params(W, H, sample_count=4, max_depth=2, seed=5, tile_size=64, shard_index=0,
+                               shard_count=world, background=(0.5, 0.6, 0.8))
+        mipt.render(ctx, sc, cam, p, film, stats=True)
+        t0 = time.perf_counter()
+        st = mipt.render(ctx, sc, cam, p, film, stats=True)
+        dt = time.perf_counter() - t0
+        rays = st.rays_primary + st.rays_bounce
+        out[f"shard_1_of_{world}"] = {"s": dt, "mrays_s": rays / dt / 1e6, "rays": rays}
+    n = film.packed_size(64, 0, 8)
+    buf = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    dt = timed(lambda: film.pack_tiles(64, 0, 8, buf.data_ptr()), ctx, 20)
+    out["pack_one_shard_ms"] = dt * 1e3
+    out["gather_bytes_per_rank"] = n * 16
+    return out
+
+
+def lucy(ctx):
+    vtx, idx, mats, mids = scenes.displaced_sphere(28_000_000, seed=7)
+    nodes, bs = build(vtx, idx, "int")
+    sc = mipt.Scene(ctx, nodes, vtx, idx, mats, mids, link_encoding=mipt.PT_LINKS_INT_BITS)
+    n = 1 << 24
+    rays = scenes.surface_rays(vtx, idx, n, seed=7)
+    d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
+    d_h = torch.empty_like(d_r)
+    stc = sc.trace_closest_device_counted(d_r.data_ptr(), n, d_h.data_ptr())
+    dt = timed(lambda: sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr()), ctx, 5)
+    hits = d_h.view(torch.int32)[:, 1]
+    return {"config": "Lucy-class stand-in, secondary rays only", "tris": int(idx.shape[0]),
+            "nodes": int(nodes.shape[0]), "bvh_build_s": bs, "rays": n, "mrays_s": n / dt / 1e6,
+            "hit_fraction": float((hits >= 0).float().mean().item()),
+            "box_tests_per_ray": stc.box_tests / n, "tri_tests_per_ray": stc.tri_tests / n,
+            "ties": stc.tie_rays}
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["cornell256", "cornell1080", "sanmiguel", "lucy"]
+    ctx = mipt.Context(0)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+    for name in which:
+        print(json.dumps(globals()[name](ctx)), flush=True)
