@@ -180,6 +180,17 @@ def main():
                          "note": "algorithmic reference-layout bytes; the 34 MB scene is cache "
                                  "resident, so this is not HBM traffic"},
         }
+        # HBM-side bytes per launch of that kernel come from hardware counters, which a
+        # benchmark cannot read on itself: they are taken from the committed rocprofv3 --pmc
+        # passes over this same command (profiles/collect_traffic.sh) when the workload matches.
+        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
+        default_workload = (args.tris, W, H, args.depth, spp) == (262144, 1920, 1080, 8, 4)
+        if os.path.exists(tpath) and default_workload and world == 1:
+            with open(tpath) as f:
+                tr = json.load(f)
+            out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"] / 1e9
+            out["roofline"]["traffic_unit"] = "GB per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)"
+            out["roofline"]["algorithmic_gb_per_launch"] = bytes_per_ray * rays / max(launches, 1) / 1e9
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, nodes, vtx, idx, mats, mids, sky)
         print(json.dumps(out), flush=True)

@@ -288,6 +288,9 @@ int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
     const std::string k(key);
     if (k == "extend.persistent") {
         ctx->extend_persistent = v != 0;
+    } else if (k == "extend.leaf_lanes") {
+        if (v < 1 || v > 64) return fail(PT_ERR_INVALID, "extend.leaf_lanes must be in [1,64]");
+        ctx->extend_leaf_lanes = (int)v;
     } else if (k == "extend.refill") {
         if (v < 1 || v > 64) return fail(PT_ERR_INVALID, "extend.refill must be in [1,64]");
         ctx->extend_refill = (int)v;
@@ -371,6 +374,8 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     void *d_nodes, *d_vtx, *d_idx, *d_wn, *d_wt, *d_mid, *d_mat;
+    if (wide.nodes.size() > (1u << 26) || wide.tris.size() > 89000000u)
+        return fail(PT_ERR_UNSUPPORTED, "pt_scene_create: scene too large for 32-bit record offsets");
     hipError_t e;
 #define UP(dst, src, bytes)                                                     \
     if ((e = upload(&dst, src, bytes)) != hipSuccess) {                         \

@@ -33,6 +33,7 @@ struct pt_context {
     int num_cus = 0;
     int extend_persistent = 1;      // option "extend.persistent"
     int extend_refill = 16;         // option "extend.refill"
+    int extend_leaf_lanes = 32;     // option "extend.leaf_lanes"
     int extend_blocks_per_cu = 6;   // option "extend.blocks_per_cu"
     mipt::DeviceTraceCounters *counters = nullptr;
     mipt::DeviceBuffer io_rays;     // staging for the host-pointer entry points
@@ -47,6 +48,7 @@ struct pt_context {
         c.num_cus = num_cus;
         c.blocks_per_cu = extend_blocks_per_cu;
         c.refill = extend_refill;
+        c.leaf_lanes = extend_leaf_lanes;
         return c;
     }
 

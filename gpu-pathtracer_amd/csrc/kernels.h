@@ -38,6 +38,7 @@ struct ExtendConfig {
     int num_cus;            // compute units of the device
     int blocks_per_cu;      // persistent form: upper bound on workgroups per compute unit
     int refill;             // persistent form: top up a wave when this many lanes are idle
+    int leaf_lanes;         // persistent form: triangle step once this many lanes wait at one
 };
 
 // Closest hit in the reference's fixed skip-link order.

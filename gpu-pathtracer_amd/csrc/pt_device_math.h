@@ -58,28 +58,24 @@ __device__ __forceinline__ bool intersect_box(const RayPre &r, float minx, float
 
 // shaders/RadeonRays/bvh.glslh:206-287.  tMax is the running nearest distance
 // (isect.uvwt.w at :268).  On a hit writes b0,b1,b2,t.
+// Written with selects and non-short-circuit predicates: the only branches left are the
+// rare fp64 edge re-evaluation and the division of an accepted hit, so a divergent wave
+// does not serialise the three axis permutations or the rejection ladder.
 __device__ __forceinline__ bool intersect_triangle_watertight(const RayPre &r, float v0x, float v0y,
                                                               float v0z, float v1x, float v1y,
                                                               float v1z, float v2x, float v2y,
                                                               float v2z, float tMax, float &b0,
                                                               float &b1, float &b2, float &t) {
-    float ax = v0x - r.ox, ay = v0y - r.oy, az = v0z - r.oz;
-    float bx = v1x - r.ox, by = v1y - r.oy, bz = v1z - r.oz;
-    float cx = v2x - r.ox, cy = v2y - r.oy, cz = v2z - r.oz;
-    float p0x, p0y, p0z, p1x, p1y, p1z, p2x, p2y, p2z;
-    if (r.axis == 0) {          // .yzx
-        p0x = ay; p0y = az; p0z = ax;
-        p1x = by; p1y = bz; p1z = bx;
-        p2x = cy; p2y = cz; p2z = cx;
-    } else if (r.axis == 1) {   // .zxy
-        p0x = az; p0y = ax; p0z = ay;
-        p1x = bz; p1y = bx; p1z = by;
-        p2x = cz; p2y = cx; p2z = cy;
-    } else {
-        p0x = ax; p0y = ay; p0z = az;
-        p1x = bx; p1y = by; p1z = bz;
-        p2x = cx; p2y = cy; p2z = cz;
-    }
+    const float ax = v0x - r.ox, ay = v0y - r.oy, az = v0z - r.oz;
+    const float bx = v1x - r.ox, by = v1y - r.oy, bz = v1z - r.oz;
+    const float cx = v2x - r.ox, cy = v2y - r.oy, cz = v2z - r.oz;
+    const bool k0 = r.axis == 0, k1 = r.axis == 1;      // 0: .yzx   1: .zxy   else identity
+    float p0x = k0 ? ay : (k1 ? az : ax), p0y = k0 ? az : (k1 ? ax : ay);
+    float p0z = k0 ? ax : (k1 ? ay : az);
+    float p1x = k0 ? by : (k1 ? bz : bx), p1y = k0 ? bz : (k1 ? bx : by);
+    float p1z = k0 ? bx : (k1 ? by : bz);
+    float p2x = k0 ? cy : (k1 ? cz : cx), p2y = k0 ? cz : (k1 ? cx : cy);
+    float p2z = k0 ? cx : (k1 ? cy : cz);
     p0x += r.sx * p0z; p0y += r.sy * p0z;
     p1x += r.sx * p1z; p1y += r.sy * p1z;
     p2x += r.sx * p2z; p2y += r.sy * p2z;
@@ -88,7 +84,7 @@ __device__ __forceinline__ bool intersect_triangle_watertight(const RayPre &r, f
     float e1 = p2x * p0y - p2y * p0x;
     float e2 = p0x * p1y - p0y * p1x;
 
-    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+    if ((e0 == 0.0f) | (e1 == 0.0f) | (e2 == 0.0f)) {
         const double p2xp1y = (double)p2x * (double)p1y;
         const double p2yp1x = (double)p2y * (double)p1x;
         e0 = (float)(p2yp1x - p2xp1y);
@@ -99,15 +95,15 @@ __device__ __forceinline__ bool intersect_triangle_watertight(const RayPre &r, f
         const double p1yp0x = (double)p1y * (double)p0x;
         e2 = (float)(p1yp0x - p1xp0y);
     }
-    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f))
-        return false;
+    const bool any_neg = (e0 < 0.0f) | (e1 < 0.0f) | (e2 < 0.0f);
+    const bool any_pos = (e0 > 0.0f) | (e1 > 0.0f) | (e2 > 0.0f);
     const float det = (e0 + e1) + e2;
-    if (det == 0.0f) return false;
-
     p0z *= r.sz; p1z *= r.sz; p2z *= r.sz;
     const float tScaled = (e0 * p0z + e1 * p1z) + e2 * p2z;
-    if (det < 0.0f && (tScaled >= 0.0f || tScaled < tMax * det)) return false;
-    else if (det > 0.0f && (tScaled <= 0.0f || tScaled > tMax * det)) return false;
+    const float lim = tMax * det;
+    const bool out_neg = (det < 0.0f) & ((tScaled >= 0.0f) | (tScaled < lim));
+    const bool out_pos = (det > 0.0f) & ((tScaled <= 0.0f) | (tScaled > lim));
+    if ((any_neg & any_pos) | (det == 0.0f) | out_neg | out_pos) return false;
 
     const float invDet = 1.0f / det;
     b0 = e0 * invDet;

@@ -105,6 +105,17 @@ __device__ __forceinline__ void traverse_skiplink(const DeviceScene &s, const fl
     }
 }
 
+// Records of the re-laid-out scene by 32-bit byte offset from a uniform base (one scalar
+// base + one vector offset per load); pt_scene_create keeps both arrays below 4 GiB.
+__device__ __forceinline__ const float4 *wide_node(const DeviceScene &s, int32_t node) {
+    return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wnodes) +
+                                            ((uint32_t)node << 6));
+}
+__device__ __forceinline__ const float4 *wide_tri(const DeviceScene &s, int32_t leaf) {
+    return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wtris) +
+                                            ((uint32_t)(~leaf) << 4));
+}
+
 // Ordered closest-hit traversal of one ray.  `stack` points at this lane's column of the
 // workgroup's LDS stack (entry e at stack[e * kTraceBlock]).  Sets `tie` when the result
 // could depend on the visiting order; the caller then re-resolves the ray with
@@ -125,7 +136,7 @@ __device__ __forceinline__ void traverse_ordered(const DeviceScene &s, const flo
     tie = false;
 
     int sp = 0;
-    int32_t cur = 0;             // >= 0: two-child node, < 0: ~triangle slot
+    int32_t cur = 0;             // >= 0: two-child node, < 0: a triangle record (see wide_tri)
     // Non-finite rays and zero directions follow whatever the shader's arithmetic makes of
     // them (a NaN distance is "accepted" once and then culls everything): that depends on
     // the visiting order, so they are left to the fixed-order traversal.
@@ -139,7 +150,7 @@ __device__ __forceinline__ void traverse_ordered(const DeviceScene &s, const flo
     }
     while (cur != kSentinel) {
         while (cur >= 0) {
-            const float4 *np = s.wnodes + 4 * (int64_t)cur;
+            const float4 *np = wide_node(s, cur);
             const float4 a = np[0], b = np[1], c = np[2];
             const int4 ch = reinterpret_cast<const int4 *>(np)[3];
             if (COUNT) nb += 2;
@@ -168,7 +179,7 @@ __device__ __forceinline__ void traverse_ordered(const DeviceScene &s, const flo
             }
         }
         while (cur < 0 && cur != kSentinel) {
-            const float4 *tp = s.wtris + 3 * (int64_t)(~cur);
+            const float4 *tp = wide_tri(s, cur);
             const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
             if (COUNT) ++nt;
             float h0, h1, h2, ht;
@@ -208,7 +219,8 @@ struct OrderedState {
     bool tie;
 };
 
-__device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro, const float4 rd) {
+__device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro, const float4 rd,
+                                              int32_t *stack) {
     st.r = precompute_ray(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
     st.tmax = ro.w;
     st.b0 = 0.f; st.b1 = 0.f; st.b2 = 0.f;
@@ -217,7 +229,8 @@ __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro,
     st.second = INFINITY;
     st.primid = -1;
     st.tie = false;
-    st.sp = 0;
+    stack[0] = kSentinel;          // bottom of the stack: popping it ends the ray
+    st.sp = 1;
     st.cur = 0;
     const float chk = ((ro.x + ro.y) + (ro.z + rd.x)) + (rd.y + rd.z);
     if (!(fabsf(chk) < INFINITY) || !(st.tmax == st.tmax) ||
@@ -227,71 +240,79 @@ __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro,
     }
 }
 
-// Advances every traversing lane of the wave until at most `min_active` of them are still
-// traversing (0: run the wave's rays to completion).
+// Advances the traversing lanes of the wave until at most `min_active` of them are still
+// traversing (0: run the wave's rays to completion).  Each round the wave votes on one step:
+// the lanes standing at a triangle take a triangle step once `leaf_lanes` of them have
+// gathered (or no lane stands at a node), otherwise the lanes standing at a node take a node
+// step.  Lanes of the other kind wait, so neither step runs for a handful of stragglers.
+// Stack slot 0 holds kSentinel (ordered_begin puts it there), so a pop needs no emptiness
+// test: popping the bottom entry ends the ray.  Both steps are written with selects; the
+// only divergent regions are the stack accesses and the work inside the triangle test.
 template <bool COUNT>
 __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedState &st,
-                                                int32_t *stack, int min_active,
+                                                int32_t *stack, int min_active, int leaf_lanes,
                                                 unsigned long long &nb, unsigned long long &nt) {
     for (;;) {
-        while (st.cur >= 0) {
-            const float4 *np = s.wnodes + 4 * (int64_t)st.cur;
-            const float4 a = np[0], b = np[1], c = np[2];
-            const int4 ch = reinterpret_cast<const int4 *>(np)[3];
-            if (COUNT) nb += 2;
-            float ta, tb;
-            const bool ha = intersect_box(st.r, a.x, a.y, a.z, a.w, c.x, c.y, st.bound, ta);
-            const bool hb = intersect_box(st.r, b.x, b.y, b.z, b.w, c.z, c.w, st.bound, tb);
-            if (ha && hb) {
-                const bool swap = tb < ta;
-                const int32_t near_c = swap ? ch.y : ch.x;
-                const int32_t far_c = swap ? ch.x : ch.y;
-                if (st.sp < kTraceStack) {
-                    stack[st.sp * kTraceBlock] = far_c;
-                    ++st.sp;
-                    st.cur = near_c;
-                } else {
-                    st.tie = true;
-                    st.cur = kSentinel;
+        const bool at_node = st.cur >= 0;
+        const bool at_leaf = (st.cur < 0) & (st.cur != kSentinel);
+        const int n_node = (int)__popcll(__ballot(at_node));
+        const int n_leaf = (int)__popcll(__ballot(at_leaf));
+        if (n_node + n_leaf <= min_active) break;
+        if (n_node != 0 && n_leaf < leaf_lanes) {
+            if (at_node) {
+                const float4 *np = wide_node(s, st.cur);
+                const float4 a = np[0], b = np[1], c = np[2];
+                const int4 ch = reinterpret_cast<const int4 *>(np)[3];
+#ifdef PT_WAVE_ITERS
+                if (COUNT && (__ffsll(__ballot(1)) - 1) == (int)(threadIdx.x & 63)) nb += 128;
+#else
+                if (COUNT) nb += 2;
+#endif
+                float ta, tb;
+                const bool ha = intersect_box(st.r, a.x, a.y, a.z, a.w, c.x, c.y, st.bound, ta);
+                const bool hb = intersect_box(st.r, b.x, b.y, b.z, b.w, c.z, c.w, st.bound, tb);
+                const bool take_b = hb & (!ha | (tb < ta));     // the nearer hit child is c1
+                const bool both = ha & hb, none = !(ha | hb);
+                const bool full = both & (st.sp > kTraceStack);
+                int32_t next = take_b ? ch.y : ch.x;
+                if (both & !full) stack[st.sp * kTraceBlock] = take_b ? ch.x : ch.y;
+                st.sp += (both & !full) ? 1 : 0;
+                st.tie |= full;
+                if (none) {
+                    --st.sp;
+                    next = stack[st.sp * kTraceBlock];
                 }
-            } else if (ha || hb) {
-                st.cur = ha ? ch.x : ch.y;
-            } else if (st.sp > 0) {
-                --st.sp;
-                st.cur = stack[st.sp * kTraceBlock];
-            } else {
-                st.cur = kSentinel;
+                st.cur = full ? kSentinel : next;
             }
-        }
-        while (st.cur < 0 && st.cur != kSentinel) {
-            const float4 *tp = s.wtris + 3 * (int64_t)(~st.cur);
+        } else if (at_leaf) {
+            const float4 *tp = wide_tri(s, st.cur);
             const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+#ifdef PT_WAVE_ITERS
+            if (COUNT && (__ffsll(__ballot(1)) - 1) == (int)(threadIdx.x & 63)) nt += 64;
+#else
             if (COUNT) ++nt;
-            float h0, h1, h2, ht;
-            if (intersect_triangle_watertight(st.r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                                              q2.x, st.bound, h0, h1, h2, ht)) {
-                if (!(ht == ht)) {
-                    st.tie = true;
-                    st.cur = kSentinel;
-                    break;
-                }
-                if (st.primid < 0 || ht < st.tbest) {
-                    if (st.primid >= 0) st.second = fminf(st.second, st.tbest);
-                    st.tbest = ht; st.b0 = h0; st.b1 = h1; st.b2 = h2;
-                    st.primid = __float_as_int(q2.y);
-                    st.bound = fminf(st.tbest + st.tbest * PT_TIE_WINDOW, st.tmax);
-                } else {
-                    st.second = fminf(st.second, ht);
-                }
-            }
-            if (st.sp > 0) {
-                --st.sp;
-                st.cur = stack[st.sp * kTraceBlock];
-            } else {
-                st.cur = kSentinel;
-            }
+#endif
+            float h0 = 0.f, h1 = 0.f, h2 = 0.f, ht = 0.f;
+            const bool hit = intersect_triangle_watertight(st.r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y,
+                                                           q1.z, q1.w, q2.x, st.bound, h0, h1, h2, ht);
+            const bool bad = hit & !(ht == ht);
+            const bool had = st.primid >= 0;
+            const bool closer = hit & !bad & (!had | (ht < st.tbest));
+            const bool farther = hit & !bad & !closer;
+            const float s_old = fminf(st.second, st.tbest), s_new = fminf(st.second, ht);
+            st.second = (closer & had) ? s_old : (farther ? s_new : st.second);
+            st.tbest = closer ? ht : st.tbest;
+            st.b0 = closer ? h0 : st.b0;
+            st.b1 = closer ? h1 : st.b1;
+            st.b2 = closer ? h2 : st.b2;
+            st.primid = closer ? __float_as_int(q2.y) : st.primid;
+            const float nbound = fminf(ht + ht * PT_TIE_WINDOW, st.tmax);
+            st.bound = closer ? nbound : st.bound;
+            st.tie |= bad;
+            --st.sp;
+            const int32_t popped = stack[st.sp * kTraceBlock];
+            st.cur = bad ? kSentinel : popped;
         }
-        if ((int)__popcll(__ballot(st.cur != kSentinel)) <= min_active) break;
     }
 }
 
@@ -374,7 +395,7 @@ __device__ __forceinline__ void count_ties(bool tie, unsigned int *tie_count) {
 template <bool COUNT>
 __device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, const pt_ray *rays,
                                                         pt_hit *hits, uint32_t n, bool fixup,
-                                                        int refill, int32_t *stack,
+                                                        int refill, int leaf_lanes, int32_t *stack,
                                                         unsigned int *tie_count,
                                                         DeviceTraceCounters *work) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -419,7 +440,7 @@ __device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, co
                 if (idx < n) {
                     const float4 ro = reinterpret_cast<const float4 *>(rays + idx)[0];
                     const float4 rd = reinterpret_cast<const float4 *>(rays + idx)[1];
-                    ordered_begin(st, ro, rd);
+                    ordered_begin(st, ro, rd, stack);
                     my_ray = idx;
                 }
             }
@@ -429,7 +450,7 @@ __device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, co
             if (pos >= stream_len) break;
             continue;                                           // tail positions past the queue end
         }
-        ordered_advance<COUNT>(s, st, stack, pos < stream_len ? 64 - refill : 0, nb, nt);
+        ordered_advance<COUNT>(s, st, stack, pos < stream_len ? 64 - refill : 0, leaf_lanes, nb, nt);
     }
     if (n_ties) atomicAdd(tie_count, n_ties);
     if (COUNT) {

@@ -107,9 +107,9 @@ __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_persi
                                                                 const unsigned int *count,
                                                                 unsigned int *tie_count,
                                                                 DeviceTraceCounters *work,
-                                                                int refill) {
-    __shared__ int32_t s_stack[kTraceStack * kBlock];
-    persistent_closest_hits<COUNT>(s, rays, hits, *count, true, refill, s_stack + threadIdx.x,
+                                                                int refill, int leaf_lanes) {
+    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];   // + the bottom sentinel
+    persistent_closest_hits<COUNT>(s, rays, hits, *count, true, refill, leaf_lanes, s_stack + threadIdx.x,
                                    tie_count, work);
 }
 
@@ -240,10 +240,10 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
             blocks(max_rays, kBlock), persistent_grid(k, kBlock, cfg, &occ[work ? 1 : 0]));
         if (work)
             hipLaunchKernelGGL(k_pt_extend_persistent<true>, dim3(grid), dim3(kBlock), 0, st, s,
-                               ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill);
+                               ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes);
         else
             hipLaunchKernelGGL(k_pt_extend_persistent<false>, dim3(grid), dim3(kBlock), 0, st, s,
-                               ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill);
+                               ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes);
         return;
     }
     if (work)

@@ -66,10 +66,10 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_ordered_persistent(DeviceScene s,
                                                                     const pt_ray *rays,
                                                                     pt_hit *hits, uint32_t n,
-                                                                    bool fixup, int refill,
+                                                                    bool fixup, int refill, int leaf_lanes,
                                                                     DeviceTraceCounters *counters) {
-    __shared__ int32_t s_stack[kTraceStack * kBlock];
-    persistent_closest_hits<COUNT>(s, rays, hits, n, fixup, refill, s_stack + threadIdx.x,
+    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];   // + the bottom sentinel
+    persistent_closest_hits<COUNT>(s, rays, hits, n, fixup, refill, leaf_lanes, s_stack + threadIdx.x,
                                    &counters->tie_count, counters);
 }
 
@@ -132,10 +132,10 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
             grid_for(n), persistent_grid(k, kBlock, cfg, &occ[count_work ? 1 : 0]));
         if (count_work)
             hipLaunchKernelGGL((k_trace_ordered_persistent<true>), dim3(grid), dim3(kBlock), 0, st,
-                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, counters);
+                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, counters);
         else
             hipLaunchKernelGGL((k_trace_ordered_persistent<false>), dim3(grid), dim3(kBlock), 0, st,
-                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, counters);
+                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, counters);
         return;
     }
     const unsigned int grid = grid_for(n);

@@ -51,7 +51,8 @@ void tree_from_skip_links(const pt_bbox *nodes, uint32_t n_nodes, uint32_t link_
 //   lo.x/y/z/w = c0.min.x, c0.max.x, c0.min.y, c0.max.y   (16-byte vector 0)
 //   hi...      = c1.min.x, c1.max.x, c1.min.y, c1.max.y   (16-byte vector 1)
 //   zz         = c0.min.z, c0.max.z, c1.min.z, c1.max.z   (16-byte vector 2)
-//   child[0..1]: >= 0 inner-node index, < 0 : ~(triangle slot);  child[2..3] unused
+//   child[0..1]: >= 0 inner-node index, < 0 : ~(3 * triangle slot), i.e. the complemented
+//   position of the 48-byte record in 16-byte units;  child[2..3] unused
 struct WideNode {
     float c0xy[4];
     float c1xy[4];

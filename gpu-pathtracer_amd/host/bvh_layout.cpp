@@ -188,7 +188,8 @@ void build_wide_layout(const BvhTree &t, const float *vtx, uint32_t n_vtx, const
         xy[0] = b.pmin[0]; xy[1] = b.pmax[0]; xy[2] = b.pmin[1]; xy[3] = b.pmax[1];
         w.cz[2 * c + 0] = b.pmin[2];
         w.cz[2 * c + 1] = b.pmax[2];
-        w.child[c] = slot[node];
+        // a leaf is named by the position of its record in 16-byte units, complemented
+        w.child[c] = slot[node] >= 0 ? slot[node] : ~(3 * ~slot[node]);
     };
 
     if (n == 1) {
@@ -200,7 +201,7 @@ void build_wide_layout(const BvhTree &t, const float *vtx, uint32_t n_vtx, const
         WideNode &w = out.nodes[0];
         set_child(w, 0, 0);
         set_child(w, 1, 0);
-        w.child[1] = ~1;
+        w.child[1] = ~3;
         w.child[2] = w.child[3] = 0;
         out.tris.assign(2, TriRecord{});
         fill_tri(0);
