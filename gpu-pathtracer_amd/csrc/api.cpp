@@ -291,6 +291,8 @@ int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
     } else if (k == "extend.leaf_lanes") {
         if (v < 1 || v > 64) return fail(PT_ERR_INVALID, "extend.leaf_lanes must be in [1,64]");
         ctx->extend_leaf_lanes = (int)v;
+    } else if (k == "any.exact_order") {
+        ctx->any_exact_order = v != 0;
     } else if (k == "extend.refill") {
         if (v < 1 || v > 64) return fail(PT_ERR_INVALID, "extend.refill must be in [1,64]");
         ctx->extend_refill = (int)v;
@@ -364,6 +366,9 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     }
     WideBvh wide;
     build_wide_layout(tree, vtx, n_vtx, idx, n_tri, wide);
+    std::vector<int32_t> light_tri;
+    std::vector<float> light_cdf;
+    build_light_list(vtx, idx, n_tri, mats.data(), mids.data(), light_tri, light_cdf);
 
     auto sc = std::make_unique<pt_scene>();
     sc->ctx = ctx;
@@ -373,7 +378,7 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
         sc->allocs.push_back(*dst);
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
-    void *d_nodes, *d_vtx, *d_idx, *d_wn, *d_wt, *d_mid, *d_mat;
+    void *d_nodes, *d_vtx, *d_idx, *d_wn, *d_wt, *d_mid, *d_mat, *d_lt = nullptr, *d_lc = nullptr;
     if (wide.nodes.size() > (1u << 26) || wide.tris.size() > 89000000u)
         return fail(PT_ERR_UNSUPPORTED, "pt_scene_create: scene too large for 32-bit record offsets");
     hipError_t e;
@@ -389,6 +394,10 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     UP(d_wt, wide.tris.data(), sizeof(TriRecord) * wide.tris.size());
     UP(d_mid, mids.data(), sizeof(int32_t) * mids.size());
     UP(d_mat, mats.data(), sizeof(pt_material) * mats.size());
+    if (!light_tri.empty()) {
+        UP(d_lt, light_tri.data(), sizeof(int32_t) * light_tri.size());
+        UP(d_lc, light_cdf.data(), sizeof(float) * light_cdf.size());
+    }
 #undef UP
     DeviceScene &d = sc->dev;
     d.nodes = (const float4 *)d_nodes;
@@ -398,6 +407,10 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     d.wtris = (const float4 *)d_wt;
     d.mat_ids = (const int32_t *)d_mid;
     d.materials = (const pt_material *)d_mat;
+    d.light_tri = (const int32_t *)d_lt;
+    d.light_cdf = (const float *)d_lc;
+    d.n_lights = (uint32_t)light_tri.size();
+    d.light_area = light_cdf.empty() ? 0.f : light_cdf.back();
     d.n_nodes = n_nodes;
     d.n_tri = n_tri;
     d.n_wnodes = (uint32_t)wide.nodes.size();
@@ -505,7 +518,7 @@ int pt_trace_any_device(pt_context *ctx, const pt_scene *scene, const pt_ray *ra
         return fail(PT_ERR_INVALID, "pt_trace_any_device: null argument");
     if (scene->ctx != ctx) return fail(PT_ERR_INVALID, "scene belongs to another context");
     HIP_CHECK(hipSetDevice(ctx->device));
-    launch_trace_any(ctx->stream, scene->dev, rays_dev, occluded_dev, n);
+    launch_trace_any(ctx->stream, scene->dev, rays_dev, occluded_dev, n, ctx->any_exact_order != 0);
     HIP_CHECK(hipGetLastError());
     return PT_OK;
 }
@@ -524,7 +537,7 @@ int pt_trace_any(pt_context *ctx, const pt_scene *scene, const pt_ray *rays, uin
     HIP_CHECK(hipMemcpyAsync(ctx->io_rays.ptr, rays, sizeof(pt_ray) * n, hipMemcpyHostToDevice,
                              ctx->stream));
     launch_trace_any(ctx->stream, scene->dev, (const pt_ray *)ctx->io_rays.ptr,
-                     (int32_t *)ctx->io_hits.ptr, n);
+                     (int32_t *)ctx->io_hits.ptr, n, ctx->any_exact_order != 0);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(occluded, ctx->io_hits.ptr, sizeof(int32_t) * n,
                              hipMemcpyDeviceToHost, ctx->stream));

@@ -33,8 +33,9 @@ struct pt_context {
     int num_cus = 0;
     int extend_persistent = 1;      // option "extend.persistent"
     int extend_refill = 16;         // option "extend.refill"
-    int extend_leaf_lanes = 32;     // option "extend.leaf_lanes"
+    int extend_leaf_lanes = 16;     // option "extend.leaf_lanes"
     int extend_blocks_per_cu = 6;   // option "extend.blocks_per_cu"
+    int any_exact_order = 0;        // option "any.exact_order"
     mipt::DeviceTraceCounters *counters = nullptr;
     mipt::DeviceBuffer io_rays;     // staging for the host-pointer entry points
     mipt::DeviceBuffer io_hits;

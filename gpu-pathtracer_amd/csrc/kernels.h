@@ -19,6 +19,11 @@ struct DeviceScene {
     const float4 *wtris;   // 3 x float4 per triangle record (48 B), leaf order
     const int32_t *mat_ids;
     const pt_material *materials;
+    // Emissive triangles (ascending) and the running sum of their areas.
+    const int32_t *light_tri;
+    const float *light_cdf;
+    uint32_t n_lights;
+    float light_area;
     uint32_t n_nodes, n_tri, n_wnodes, n_materials;
     uint32_t link_enc;
     uint32_t wide_depth;
@@ -56,8 +61,10 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
 // resident: compute units x min(cap, what the occupancy query admits).
 unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg, int *cache);
 
+// Occlusion query.  exact_order: walk the skip links as the reference does; otherwise the
+// two-child nodes, nearer child first (the answer is the same).
 void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, int32_t *occluded,
-                      uint64_t n);
+                      uint64_t n, bool exact_order);
 
 void launch_raygen(hipStream_t st, const pt_camera &cam, uint32_t width, uint32_t height,
                    pt_ray *rays);

@@ -35,8 +35,9 @@ __host__ __device__ __forceinline__ float rnd(uint32_t key, uint32_t dim) {
     const uint32_t r = mix32(key ^ (dim * 0x85EBCA6BU + 1U));
     return (float)(r >> 8) * 5.9604644775390625e-08f;   // 2^-24
 }
-// Dimension layout: 0,1 pixel jitter; bounce b uses 2+6b .. 7+6b:
-enum { DIM_LOBE = 0, DIM_U1 = 1, DIM_U2 = 2, DIM_RR = 3, DIM_L1 = 4, DIM_L2 = 5, DIMS_PER_BOUNCE = 6 };
+// Dimension layout: 0,1 pixel jitter; bounce b uses 2+8b .. 9+8b:
+enum { DIM_LOBE = 0, DIM_U1 = 1, DIM_U2 = 2, DIM_RR = 3, DIM_LSEL = 4, DIM_L1 = 5, DIM_L2 = 6,
+       DIMS_PER_BOUNCE = 8 };
 
 // ---- cos/sin of 2*pi*u, u in [0,1): quadrant folding + Taylor polynomials on [0, pi/4] --
 __device__ __forceinline__ float poly_sin(float y) {   // y in [0, pi/4]
@@ -103,35 +104,112 @@ __device__ __forceinline__ void basis(V3 n, V3 &t, V3 &b) {
     b = v3(bb, sign + (n.y * n.y) * a, -n.y);
 }
 
+// Emissive triangles of a scene, for next-event estimation: triangle indices in ascending
+// order and the running sum of their areas (binary32, summed in that order).
+struct LightList {
+    const int32_t *tri;
+    const float *cdf;
+    uint32_t count;
+    float area;        // cdf[count - 1]
+};
+
+#define PT_INV_PI 0.31830988618379067f
+
+// Area of a triangle from its un-normalised normal c = (v1-v0) x (v2-v0).
+__host__ __device__ __forceinline__ float tri_area_from_len2(float len2) { return 0.5f * sqrtf(len2); }
+
+// Index of the first entry of cdf[0..n) that exceeds x (n - 1 if none does).
+__host__ __device__ __forceinline__ uint32_t cdf_find(const float *cdf, uint32_t n, float x) {
+    uint32_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] > x) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+// Power-heuristic weight of a sample drawn with density `mine` against a competing
+// technique of density `other`, written so that an infinite density gives 0 or 1, not NaN.
+__device__ __forceinline__ float mis_weight(float mine, float other) {
+    const float r = other / mine;
+    return 1.0f / (1.0f + r * r);
+}
+
 // Outcome of shading one path vertex.
 struct ShadeResult {
     V3 emitted;      // radiance to add, already multiplied by the incoming throughput
     V3 throughput;   // throughput after this vertex (valid if alive)
     V3 o, d;         // next ray (valid if alive)
+    float q;         // density the next direction was drawn with (lobe probability included)
     bool alive;
+    bool shadow;     // a shadow ray was generated:
+    V3 so, sd;       //   its origin and unit direction
+    float smax;      //   its extent (<= 0: nothing can lie in between, count it unoccluded)
+    V3 direct;       //   radiance to add if it reaches the light
 };
+
+// Triangle vertices by index.
+struct TriVerts { V3 v0, v1, v2; };
+__device__ __forceinline__ TriVerts fetch_tri(const float *vtx, const int32_t *idx, int32_t tri) {
+    const int64_t t3 = 3 * (int64_t)tri;
+    const float *p0 = vtx + 3 * (int64_t)idx[t3 + 0], *p1 = vtx + 3 * (int64_t)idx[t3 + 1],
+                *p2 = vtx + 3 * (int64_t)idx[t3 + 2];
+    TriVerts r;
+    r.v0 = v3(p0[0], p0[1], p0[2]);
+    r.v1 = v3(p1[0], p1[1], p1[2]);
+    r.v2 = v3(p2[0], p2[1], p2[2]);
+    return r;
+}
 
 // One path vertex.  wi is sampled from the Lambert lobe (cosine-weighted) or the GGX lobe
 // (half-vector sampling of the NDF), chosen with probability proportional to the lobes'
 // summed reflectances.  bounce = index of this vertex (0 = first hit).
+//
+// With next-event estimation (nee, and the scene has emissive triangles) the vertex also
+// aims one shadow ray at a point drawn uniformly by area from the emissive triangles, and
+// light reached by a sampled direction is weighted against that technique: `q_in` is the
+// density the incoming direction was drawn with (<= 0: a camera ray, weight 1), t_hit the
+// distance it travelled.  Each lobe is weighted separately, with the lobe's selection
+// probability folded into its density.
 __device__ __forceinline__ ShadeResult shade_vertex(const pt_material &m, V3 v0, V3 v1, V3 v2,
                                                     float b0, float b1, float b2, V3 rd,
                                                     V3 thr, uint32_t key, uint32_t bounce,
                                                     uint32_t max_depth, uint32_t rr_start,
-                                                    float ray_offset) {
+                                                    float ray_offset, bool nee,
+                                                    const LightList &lights, const float *vtx,
+                                                    const int32_t *idx,
+                                                    const pt_material *materials,
+                                                    const int32_t *mat_ids, float q_in,
+                                                    float t_hit) {
     ShadeResult r;
     r.alive = false;
+    r.shadow = false;
     r.throughput = thr;
     r.o = v3(0, 0, 0);
     r.d = v3(0, 0, 0);
+    r.so = v3(0, 0, 0);
+    r.sd = v3(0, 0, 0);
+    r.direct = v3(0, 0, 0);
+    r.smax = 0.0f;
+    r.q = -1.0f;
     const V3 ke = v3(m.ke[0], m.ke[1], m.ke[2]);
     r.emitted = vmul(thr, ke);
+    V3 ng = vcross(vsub(v1, v0), vsub(v2, v0));
+    const float len2 = vdot(ng, ng);
+    const bool use_nee = nee && lights.count > 0;
+    if (use_nee && q_in > 0.0f && (ke.x + ke.y) + ke.z > 0.0f && len2 > 0.0f) {
+        // This triangle is in the light list: weight the hit against having sampled it.
+        const float cos_l = fabsf(vdot(ng, rd)) / sqrtf(len2);
+        if (cos_l > 0.0f) {
+            const float pl = (t_hit * t_hit) / (cos_l * lights.area);
+            r.emitted = vscale(r.emitted, mis_weight(q_in, pl));
+        }
+    }
     if (bounce + 1 >= max_depth) return r;
 
     // geometry
     const V3 p = vcomb3(v0, b0, v1, b1, v2, b2);
-    V3 ng = vcross(vsub(v1, v0), vsub(v2, v0));
-    const float len2 = vdot(ng, ng);
     if (!(len2 > 0.0f)) return r;                       // degenerate triangle: absorb
     ng = vdiv(ng, sqrtf(len2));
     const V3 n = vdot(ng, rd) > 0.0f ? v3(-ng.x, -ng.y, -ng.z) : ng;
@@ -148,6 +226,72 @@ __device__ __forceinline__ ShadeResult shade_vertex(const pt_material &m, V3 v0,
     if (!(wsum > 0.0f)) return r;                       // black surface
     const float p_spec = ws / wsum;
     const uint32_t dim0 = 2u + bounce * (uint32_t)DIMS_PER_BOUNCE;
+    const float rough = fminf(fmaxf(m.roughness, 0.03f), 1.0f);
+    const float alpha = rough * rough;
+    const float a2 = alpha * alpha;
+    const float big = fmaxf(1.0f, fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
+    const float offs = ray_offset * big;
+    const V3 org = v3(p.x + n.x * offs, p.y + n.y * offs, p.z + n.z * offs);
+
+    // next-event estimation
+    if (use_nee) {
+        const float u_sel = rnd(key, dim0 + DIM_LSEL);
+        const float ua = rnd(key, dim0 + DIM_L1);
+        const float ub = rnd(key, dim0 + DIM_L2);
+        const uint32_t li = cdf_find(lights.cdf, lights.count, u_sel * lights.area);
+        const int32_t lt = lights.tri[li];
+        const TriVerts L = fetch_tri(vtx, idx, lt);
+        const float su = sqrtf(ua);
+        const float c0 = 1.0f - su, c1 = ub * su;
+        const float c2 = (1.0f - c0) - c1;
+        const V3 y = vcomb3(L.v0, c0, L.v1, c1, L.v2, c2);
+        const V3 dv = vsub(y, org);
+        const float dist2 = vdot(dv, dv);
+        const V3 lc = vcross(vsub(L.v1, L.v0), vsub(L.v2, L.v0));
+        const float ll2 = vdot(lc, lc);
+        if (dist2 > 0.0f && ll2 > 0.0f) {
+            const float dist = sqrtf(dist2);
+            const V3 wi = vdiv(dv, dist);
+            const float n_wi = vdot(n, wi);
+            const float cos_l = fabsf(vdot(lc, wi)) / sqrtf(ll2);
+            const float pl = dist2 / (cos_l * lights.area);
+            if (n_wi > 0.0f && cos_l > 0.0f && pl > 0.0f) {
+                const pt_material lm = materials[mat_ids[lt]];
+                // Lambert lobe
+                const float qd = (1.0f - p_spec) * (n_wi * PT_INV_PI);
+                V3 f = vscale(kd, (n_wi * PT_INV_PI) * mis_weight(pl, qd));
+                // GGX lobe
+                const V3 hv = v3(wo.x + wi.x, wo.y + wi.y, wo.z + wi.z);
+                const float hl2 = vdot(hv, hv);
+                if (ws > 0.0f && hl2 > 0.0f) {
+                    const V3 h = vdiv(hv, sqrtf(hl2));
+                    const float n_h = vdot(n, h), wo_h = vdot(wo, h);
+                    if (n_h > 0.0f && wo_h > 0.0f) {
+                        const float tt = (n_h * n_h) * (a2 - 1.0f) + 1.0f;
+                        const float D = (a2 * PT_INV_PI) / (tt * tt);
+                        const float om = 1.0f - wo_h;
+                        const float om2 = om * om;
+                        const float om5 = (om2 * om2) * om;
+                        const V3 F = v3(ks.x + (1.0f - ks.x) * om5, ks.y + (1.0f - ks.y) * om5,
+                                        ks.z + (1.0f - ks.z) * om5);
+                        const float g1o = (2.0f * n_wo) / (n_wo + sqrtf(a2 + (1.0f - a2) * (n_wo * n_wo)));
+                        const float g1i = (2.0f * n_wi) / (n_wi + sqrtf(a2 + (1.0f - a2) * (n_wi * n_wi)));
+                        const float qs = p_spec * ((D * n_h) / (4.0f * wo_h));
+                        // f_s * n_wi = F D G / (4 n_wo)
+                        const float fs = (((D * g1o) * g1i) / (4.0f * n_wo)) * mis_weight(pl, qs);
+                        f = v3(f.x + F.x * fs, f.y + F.y * fs, f.z + F.z * fs);
+                    }
+                }
+                const V3 le = v3(lm.ke[0], lm.ke[1], lm.ke[2]);
+                r.direct = vdiv(vmul(vmul(thr, f), le), pl);
+                r.shadow = vmax3(r.direct) > 0.0f;
+                r.so = org;
+                r.sd = wi;
+                r.smax = dist * 0.999f - 2e-4f;
+            }
+        }
+    }
+
     const float u_lobe = rnd(key, dim0 + DIM_LOBE);
     const float u1 = rnd(key, dim0 + DIM_U1);
     const float u2 = rnd(key, dim0 + DIM_U2);
@@ -157,11 +301,9 @@ __device__ __forceinline__ ShadeResult shade_vertex(const pt_material &m, V3 v0,
     basis(n, t, b);
 
     V3 wi, weight;
+    float q;
     if (u_lobe < p_spec) {
         // GGX: sample the half vector from D(h) (n.h), reflect wo about it.
-        const float rough = fminf(fmaxf(m.roughness, 0.03f), 1.0f);
-        const float alpha = rough * rough;
-        const float a2 = alpha * alpha;
         const float cos2 = (1.0f - u1) / (1.0f + (a2 - 1.0f) * u1);
         const float cos_h = sqrtf(cos2);
         const float sin_h = sqrtf(fmaxf(0.0f, 1.0f - cos2));
@@ -181,30 +323,33 @@ __device__ __forceinline__ ShadeResult shade_vertex(const pt_material &m, V3 v0,
         const float g1i = (2.0f * n_wi) / (n_wi + sqrtf(a2 + (1.0f - a2) * (n_wi * n_wi)));
         const float w = ((g1o * g1i) * wo_h) / ((n_wo * n_h) * p_spec);
         weight = vscale(F, w);
+        const float tt = (n_h * n_h) * (a2 - 1.0f) + 1.0f;
+        const float D = (a2 * PT_INV_PI) / (tt * tt);
+        q = p_spec * ((D * n_h) / (4.0f * wo_h));
     } else {
         const float rr = sqrtf(u1);
         const float z = sqrtf(fmaxf(0.0f, 1.0f - u1));
         wi = vcomb3(t, rr * cphi, b, rr * sphi, n, z);
         weight = vdiv(kd, 1.0f - p_spec);
+        q = (1.0f - p_spec) * (z * PT_INV_PI);
     }
     V3 nthr = vmul(thr, weight);
 
     // Russian roulette
     if (bounce >= rr_start) {
-        const float q = fminf(vmax3(nthr), 0.95f);
+        const float qq = fminf(vmax3(nthr), 0.95f);
         const float u_rr = rnd(key, dim0 + DIM_RR);
-        if (!(u_rr < q)) return r;
-        nthr = vdiv(nthr, q);
+        if (!(u_rr < qq)) return r;
+        nthr = vdiv(nthr, qq);
     }
     if (!(vmax3(nthr) > 0.0f)) return r;
 
     const float wl = sqrtf(vdot(wi, wi));
     if (!(wl > 0.0f)) return r;
-    const float big = fmaxf(1.0f, fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
-    const float offs = ray_offset * big;
-    r.o = v3(p.x + n.x * offs, p.y + n.y * offs, p.z + n.z * offs);
+    r.o = org;
     r.d = vdiv(wi, wl);
     r.throughput = nthr;
+    r.q = q > 0.0f ? q : -1.0f;
     r.alive = true;
     return r;
 }

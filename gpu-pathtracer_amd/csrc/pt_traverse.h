@@ -380,6 +380,64 @@ __device__ __forceinline__ bool occluded_skiplink(const DeviceScene &s, const fl
     return false;
 }
 
+// The same predicate over the two-child nodes, nearer child first.  Nothing shrinks during
+// an any-hit query, so which triangles get tested does not depend on the visiting order: a
+// triangle is tested exactly when every box on the way to it passes the slab test against
+// r.o.w, in the skip-link order and in this one alike (a child's box lies inside its
+// parent's, and the slab arithmetic is monotonic in the plane positions).  Rays the
+// argument does not cover (non-finite, zero direction) and rays that overflow the stack
+// take the skip-link walk.  Not for single-triangle scenes: their filler record is only
+// safe under the watertight test.
+__device__ __forceinline__ bool occluded_wide(const DeviceScene &s, const float4 ro,
+                                              const float4 rd, int32_t *stack) {
+    const float chk = ((ro.x + ro.y) + (ro.z + rd.x)) + (rd.y + rd.z);
+    if (!(fabsf(chk) < INFINITY) || !(ro.w == ro.w) ||
+        (rd.x == 0.f && rd.y == 0.f && rd.z == 0.f))
+        return occluded_skiplink(s, ro, rd);
+    RayPre r;
+    r.ox = ro.x; r.oy = ro.y; r.oz = ro.z;
+    r.ix = 1.0f / rd.x; r.iy = 1.0f / rd.y; r.iz = 1.0f / rd.z;   // :380
+    r.sx = r.sy = r.sz = 0.f;
+    r.axis = 2;
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float4 *np = wide_node(s, cur);
+            const float4 a = np[0], b = np[1], c = np[2];
+            const int4 ch = reinterpret_cast<const int4 *>(np)[3];
+            float ta, tb;
+            const bool ha = intersect_box(r, a.x, a.y, a.z, a.w, c.x, c.y, ro.w, ta);
+            const bool hb = intersect_box(r, b.x, b.y, b.z, b.w, c.z, c.w, ro.w, tb);
+            if (ha && hb) {
+                if (sp >= kTraceStack) return occluded_skiplink(s, ro, rd);
+                const bool swap = tb < ta;
+                stack[sp * kTraceBlock] = swap ? ch.x : ch.y;
+                ++sp;
+                cur = swap ? ch.y : ch.x;
+                continue;
+            }
+            if (ha || hb) {
+                cur = ha ? ch.x : ch.y;
+                continue;
+            }
+        } else {
+            const float4 *tp = wide_tri(s, cur);
+            const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+            float m1, m2, temp;
+            moller_trumbore(r.ox, r.oy, r.oz, rd.x, rd.y, rd.z, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y,
+                            q1.z, q1.w, q2.x, m1, m2, temp);
+            if (!(m1 < -PT_MT_EPS || m1 > 1.f + PT_MT_EPS || m2 < -PT_MT_EPS ||
+                  m1 + m2 > 1.f + PT_MT_EPS || temp < -PT_MT_EPS ||
+                  temp > ro.w + PT_MT_EPS))                  // :301
+                return true;
+        }
+        if (sp == 0) return false;
+        --sp;
+        cur = stack[sp * kTraceBlock];
+    }
+}
+
 __device__ __forceinline__ void count_ties(bool tie, unsigned int *tie_count) {
     const unsigned long long m = __ballot(tie);
     if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1)

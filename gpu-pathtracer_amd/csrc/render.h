@@ -44,6 +44,10 @@ struct RenderWorkspace {
     float4 *throughput;     // per path
     float4 *radiance;       // per path: radiance gathered so far
     uint32_t *key;          // per path: random-number key
+    // Next-event estimation (null when off): shadow rays of the current bounce by shadow-
+    // queue slot, and per slot the radiance the ray carries (xyz) and its path id (w, bits).
+    pt_ray *shadow_rays;
+    float4 *shadow_carry;
 };
 
 struct RenderLaunch {
@@ -61,7 +65,11 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
                       DeviceTraceCounters *work, const ExtendConfig &cfg);
 void launch_pt_shade(hipStream_t st, const DeviceScene &s, const RenderLaunch &rl,
                      const RenderWorkspace &ws, int buf_in, const unsigned int *count_in,
-                     unsigned int *count_out, uint64_t max_rays, uint32_t bounce);
+                     unsigned int *count_out, unsigned int *shadow_count, uint64_t max_rays,
+                     uint32_t bounce);
+// Shadow rays of one bounce: radiance[path] += carried radiance of every unoccluded ray.
+void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspace &ws,
+                       const unsigned int *shadow_count, uint64_t max_rays);
 void launch_pt_shade_depth(hipStream_t st, const RenderWorkspace &ws, const unsigned int *count,
                            uint64_t max_rays);
 void launch_pt_accumulate(hipStream_t st, const RenderLaunch &rl, const RenderWorkspace &ws,

@@ -8,7 +8,7 @@
 // Data layout in HBM: rays and hits are 32-byte records indexed by queue slot (one
 // coalesced 2 KiB run per wavefront); path state (throughput, radiance, key) is indexed by
 // path id and reached through the queue's path-id array.  Queues are compacted with one
-// atomic per wavefront (ballot + prefix count).
+// atomic per workgroup (ballot + prefix count per wave, prefix over the waves in LDS).
 #include "render.h"
 
 #include <algorithm>
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kWideBlock) void k_pt_raygen(RenderLaunch rl, Rende
             }
             make_camera_ray(rl.cam, rl.map.width, rl.map.height, (float)x + jx, (float)y + jy, o, d);
             ws.key[i] = key;
-            ws.throughput[i] = make_float4(1.f, 1.f, 1.f, 0.f);
+            ws.throughput[i] = make_float4(1.f, 1.f, 1.f, -1.f);   // w: density of the last sampled direction
         }
         ws.radiance[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -117,14 +117,18 @@ __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_persi
 __global__ __launch_bounds__(kWideBlock) void k_pt_shade(DeviceScene s, RenderLaunch rl,
                                                          RenderWorkspace ws, int buf_in,
                                                          const unsigned int *count_in,
-                                                         unsigned int *count_out, uint32_t bounce) {
+                                                         unsigned int *count_out,
+                                                         unsigned int *shadow_count,
+                                                         uint32_t bounce) {
     __shared__ unsigned int s_q[17];
+    const bool nee = (rl.p.flags & PT_RENDER_NEE) != 0 && s.n_lights > 0;
     const uint64_t i = (uint64_t)blockIdx.x * kWideBlock + threadIdx.x;
     const uint64_t n = *count_in;
     if ((uint64_t)blockIdx.x * kWideBlock >= n) return;
-    bool alive = false;
+    bool alive = false, shadow = false;
     uint32_t pid = 0;
-    V3 no = v3(0, 0, 0), nd = v3(0, 0, 0);
+    V3 no = v3(0, 0, 0), nd = v3(0, 0, 0), so = v3(0, 0, 0), sd = v3(0, 0, 0), carry = v3(0, 0, 0);
+    float smax = 0.f;
     if (i < n) {
         pid = ws.queue[buf_in][i];
         const int4 hi = reinterpret_cast<const int4 *>(ws.hits + i)[0];
@@ -138,23 +142,35 @@ __global__ __launch_bounds__(kWideBlock) void k_pt_shade(DeviceScene s, RenderLa
             L.z += thr.z * rl.p.background[2];
         } else {
             const float4 rd4 = reinterpret_cast<const float4 *>(ws.rays[buf_in] + i)[1];
-            const int64_t t3 = 3 * (int64_t)hi.y;
-            const int32_t i0 = s.idx[t3 + 0], i1 = s.idx[t3 + 1], i2 = s.idx[t3 + 2];
-            const float *p0 = s.vtx + 3 * (int64_t)i0, *p1 = s.vtx + 3 * (int64_t)i1,
-                        *p2 = s.vtx + 3 * (int64_t)i2;
+            const TriVerts tv = fetch_tri(s.vtx, s.idx, hi.y);
             const pt_material m = s.materials[s.mat_ids[hi.y]];
+            LightList lights;
+            lights.tri = s.light_tri;
+            lights.cdf = s.light_cdf;
+            lights.count = s.n_lights;
+            lights.area = s.light_area;
             const ShadeResult r = shade_vertex(
-                m, v3(p0[0], p0[1], p0[2]), v3(p1[0], p1[1], p1[2]), v3(p2[0], p2[1], p2[2]), hu.x,
-                hu.y, hu.z, v3(rd4.x, rd4.y, rd4.z), thr, ws.key[pid], bounce, rl.p.max_depth,
-                rl.p.rr_start_depth, rl.p.ray_offset);
+                m, tv.v0, tv.v1, tv.v2, hu.x, hu.y, hu.z, v3(rd4.x, rd4.y, rd4.z), thr, ws.key[pid],
+                bounce, rl.p.max_depth, rl.p.rr_start_depth, rl.p.ray_offset, nee, lights, s.vtx,
+                s.idx, s.materials, s.mat_ids, thr4.w, hu.w);
             L.x += r.emitted.x;
             L.y += r.emitted.y;
             L.z += r.emitted.z;
             alive = r.alive;
             if (alive) {
-                ws.throughput[pid] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, 0.f);
+                ws.throughput[pid] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, r.q);
                 no = r.o;
                 nd = r.d;
+            }
+            if (r.shadow) {
+                if (r.smax > 0.0f) {
+                    shadow = true;
+                    so = r.so; sd = r.sd; carry = r.direct; smax = r.smax;
+                } else {                                    // no room for an occluder
+                    L.x += r.direct.x;
+                    L.y += r.direct.y;
+                    L.z += r.direct.z;
+                }
             }
         }
         ws.radiance[pid] = L;
@@ -165,6 +181,39 @@ __global__ __launch_bounds__(kWideBlock) void k_pt_shade(DeviceScene s, RenderLa
         r[0] = make_float4(no.x, no.y, no.z, 1e30f);
         r[1] = make_float4(nd.x, nd.y, nd.z, 0.f);
         ws.queue[buf_in ^ 1][slot] = pid;
+    }
+    if (nee) {
+        const uint32_t ss = block_queue_append(shadow, shadow_count, s_q);
+        if (shadow) {
+            float4 *r = reinterpret_cast<float4 *>(ws.shadow_rays + ss);
+            r[0] = make_float4(so.x, so.y, so.z, smax);
+            r[1] = make_float4(sd.x, sd.y, sd.z, 0.f);
+            ws.shadow_carry[ss] = make_float4(carry.x, carry.y, carry.z, __uint_as_float(pid));
+        }
+    }
+}
+
+// occlude: IntersectSceneAny (shaders/RadeonRays/bvh.glslh:378-414) for the shadow rays of one
+// bounce; a ray that reaches its light adds the radiance it carries to its path.  A path has
+// at most one shadow ray per bounce, so the additions to a path are ordered by the launches.
+__global__ __launch_bounds__(kBlock) void k_pt_occlude(DeviceScene s, RenderWorkspace ws,
+                                                       const unsigned int *count, bool wide) {
+    __shared__ int32_t s_stack[kTraceStack * kBlock];
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t n = *count;
+    if (i >= n) return;
+    const float4 ro = reinterpret_cast<const float4 *>(ws.shadow_rays + i)[0];
+    const float4 rd = reinterpret_cast<const float4 *>(ws.shadow_rays + i)[1];
+    const bool occ = wide ? occluded_wide(s, ro, rd, s_stack + threadIdx.x)
+                          : occluded_skiplink(s, ro, rd);
+    if (!occ) {
+        const float4 c = ws.shadow_carry[i];
+        const uint32_t pid = __float_as_uint(c.w);
+        float4 L = ws.radiance[pid];
+        L.x += c.x;
+        L.y += c.y;
+        L.z += c.z;
+        ws.radiance[pid] = L;
     }
 }
 
@@ -256,10 +305,18 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
 
 void launch_pt_shade(hipStream_t st, const DeviceScene &s, const RenderLaunch &rl,
                      const RenderWorkspace &ws, int buf_in, const unsigned int *count_in,
-                     unsigned int *count_out, uint64_t max_rays, uint32_t bounce) {
+                     unsigned int *count_out, unsigned int *shadow_count, uint64_t max_rays,
+                     uint32_t bounce) {
     if (!max_rays) return;
     hipLaunchKernelGGL(k_pt_shade, dim3(blocks(max_rays, kWideBlock)), dim3(kWideBlock), 0, st, s,
-                       rl, ws, buf_in, count_in, count_out, bounce);
+                       rl, ws, buf_in, count_in, count_out, shadow_count, bounce);
+}
+
+void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspace &ws,
+                       const unsigned int *shadow_count, uint64_t max_rays) {
+    if (!max_rays) return;
+    hipLaunchKernelGGL(k_pt_occlude, dim3(blocks(max_rays, kBlock)), dim3(kBlock), 0, st, s, ws,
+                       shadow_count, s.n_tri >= 2);
 }
 
 void launch_pt_shade_depth(hipStream_t st, const RenderWorkspace &ws, const unsigned int *count,

@@ -198,8 +198,6 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
     pt_render_params p = *params;
     if (p.width != film->width || p.height != film->height)
         return fail(PT_ERR_INVALID, "pt_render: params and film disagree on the image size");
-    if (p.flags & PT_RENDER_NEE)
-        return fail(PT_ERR_UNSUPPORTED, "pt_render: next-event estimation is not implemented");
     const bool depth_mode = (p.flags & PT_RENDER_DEPTH_GREY) != 0;
     if (depth_mode) {
         p.sample_count = 1;
@@ -243,6 +241,9 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
     const size_t o_q0 = take(4 * max_paths), o_q1 = take(4 * max_paths);
     const size_t o_h = take(sizeof(pt_hit) * max_paths);
     const size_t o_t = take(16 * max_paths), o_L = take(16 * max_paths), o_k = take(4 * max_paths);
+    const bool nee = !depth_mode && (p.flags & PT_RENDER_NEE) && scene->dev.n_lights > 0;
+    const size_t o_sr = nee ? take(sizeof(pt_ray) * max_paths) : 0;
+    const size_t o_sc = nee ? take(16 * max_paths) : 0;
     rc = ctx->render_ws.reserve(off);
     if (rc != PT_OK) return rc;
     char *base = (char *)ctx->render_ws.ptr;
@@ -255,9 +256,12 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
     ws.throughput = (float4 *)(base + o_t);
     ws.radiance = (float4 *)(base + o_L);
     ws.key = (uint32_t *)(base + o_k);
+    ws.shadow_rays = nee ? (pt_ray *)(base + o_sr) : nullptr;
+    ws.shadow_carry = nee ? (float4 *)(base + o_sc) : nullptr;
 
-    // Queue sizes: one row of max_depth+1 counters per pass, plus the tie counter.
-    const uint32_t row = p.max_depth + 1;
+    // Queue sizes: per pass one row of max_depth+1 ray counters followed by max_depth
+    // shadow-ray counters; the tie counter comes last.
+    const uint32_t row = 2 * p.max_depth + 1;
     const size_t n_counts = (size_t)n_pass * row + 1;
     rc = ctx->render_counts.reserve(sizeof(unsigned int) * n_counts);
     if (rc != PT_OK) return rc;
@@ -296,7 +300,9 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
             if (depth_mode) {
                 launch_pt_shade_depth(st, ws, &c[b], paths);
             } else {
-                launch_pt_shade(st, scene->dev, rl, ws, buf, &c[b], &c[b + 1], paths, b);
+                unsigned int *sc = &c[p.max_depth + 1 + b];
+                launch_pt_shade(st, scene->dev, rl, ws, buf, &c[b], &c[b + 1], sc, paths, b);
+                if (nee && b + 1 < p.max_depth) launch_pt_occlude(st, scene->dev, ws, sc, paths);
                 buf ^= 1;
             }
         }
@@ -314,6 +320,7 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
             stats->paths += c[0];
             stats->rays_primary += c[0];
             for (uint32_t b = 1; b < p.max_depth; ++b) stats->rays_bounce += c[b];
+            for (uint32_t b = 0; b < p.max_depth; ++b) stats->rays_shadow += c[p.max_depth + 1 + b];
         }
         stats->tie_rays = h[(size_t)n_pass * row];
         if (work) {

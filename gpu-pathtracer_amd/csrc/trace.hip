@@ -74,13 +74,17 @@ __global__ __launch_bounds__(kBlock) void k_trace_ordered_persistent(DeviceScene
 }
 
 // IntersectSceneAny, shaders/RadeonRays/bvh.glslh:378-414 (leaf test :350-375, :289-310).
+// wide: walk the two-child nodes nearer child first (same answer, see occluded_wide).
 __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene s, const pt_ray *rays,
-                                                     int32_t *occluded, uint64_t n) {
+                                                     int32_t *occluded, uint64_t n, bool wide) {
+    __shared__ int32_t s_stack[kTraceStack * kBlock];
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 ro = reinterpret_cast<const float4 *>(rays + i)[0];
     const float4 rd = reinterpret_cast<const float4 *>(rays + i)[1];
-    occluded[i] = occluded_skiplink(s, ro, rd) ? 1 : 0;
+    const bool occ = wide ? occluded_wide(s, ro, rd, s_stack + threadIdx.x)
+                          : occluded_skiplink(s, ro, rd);
+    occluded[i] = occ ? 1 : 0;
 }
 
 inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kBlock - 1) / kBlock); }
@@ -148,9 +152,11 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
 }
 
 void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, int32_t *occluded,
-                      uint64_t n) {
+                      uint64_t n, bool exact_order) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays, occluded, n);
+    const bool wide = !exact_order && s.n_tri >= 2;
+    hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays, occluded, n,
+                       wide);
 }
 
 } // namespace mipt

@@ -79,6 +79,12 @@ struct WideBvh {
 void build_wide_layout(const BvhTree &t, const float *vtx, uint32_t n_vtx, const int32_t *idx,
                        uint32_t n_tri, WideBvh &out);
 
+// Emissive triangles with non-zero area, ascending, and the running binary32 sum of their
+// areas (host/lights.cpp).
+void build_light_list(const float *vtx, const int32_t *idx, uint32_t n_tri,
+                      const pt_material *materials, const int32_t *material_ids,
+                      std::vector<int32_t> &tri, std::vector<float> &cdf);
+
 // String-keyed options as the reference sets them on RadeonRays::Options
 // (src/bvh/bvh_builder.cpp:18-32, src/main_granite.cpp:175-176).
 bool set_option(pt_bvh_options &opt, const std::string &key, const std::string &value,

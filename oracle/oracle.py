@@ -191,7 +191,7 @@ def render(nodes, vtx, idx, materials, material_ids, cam, params, film=None, rec
     Adds into `film` ([H, W, 4] float32) and returns (film, rays_traced)."""
     L = lib()
     L.os_render.restype = C.c_uint64
-    L.os_render.argtypes = [C.c_void_p] * 7 + [C.c_uint32] * 4 + [C.c_void_p, C.c_int]
+    L.os_render.argtypes = [C.c_void_p] * 7 + [C.c_uint32] * 4 + [C.c_void_p, C.c_int, C.c_uint32]
     nodes, vtx, idx = _c(nodes, bbox_dtype), _c(vtx, np.float32), _c(idx, np.int32)
     mats, mids = _c(materials, material_dtype), _c(material_ids, np.int32)
     assert C.sizeof(cam) == C.sizeof(ShadeCamera) and C.sizeof(params) == C.sizeof(ShadeParams)
@@ -201,7 +201,7 @@ def render(nodes, vtx, idx, materials, material_ids, cam, params, film=None, rec
     x0, y0, x1, y1 = rect if rect is not None else (0, 0, W, H)
     rays = L.os_render(nodes.ctypes.data, vtx.ctypes.data, idx.ctypes.data, mats.ctypes.data,
                        mids.ctypes.data, C.addressof(cam), C.addressof(params), x0, y0, x1, y1,
-                       film.ctypes.data, nthreads)
+                       film.ctypes.data, nthreads, idx.shape[0])
     return film, int(rays)
 
 

@@ -38,7 +38,12 @@ typedef struct {
 } os_params;
 
 #define OS_FLAG_DEPTH_GREY 1u
+#define OS_FLAG_NEE 2u
 #define OS_FLAG_PIXEL_CENTRE 4u
+
+/* Emissive triangles with non-zero area in ascending order, and the running binary32 sum
+ * of their areas. */
+typedef struct { int32_t *tri; float *cdf; uint32_t count; float area; } os_lights;
 
 /* ---- random numbers ---------------------------------------------------------------- */
 static uint32_t mix32(uint32_t x)
@@ -127,20 +132,81 @@ static void basis(v3 n, v3 *t, v3 *b)
     *b = V(bb, sign + (n.y * n.y) * a, -n.y);
 }
 
-enum { DIM_LOBE = 0, DIM_U1 = 1, DIM_U2 = 2, DIM_RR = 3, DIMS_PER_BOUNCE = 6 };
+enum { DIM_LOBE = 0, DIM_U1 = 1, DIM_U2 = 2, DIM_RR = 3, DIM_LSEL = 4, DIM_L1 = 5, DIM_L2 = 6,
+       DIMS_PER_BOUNCE = 8 };
+
+#define OS_INV_PI 0.31830988618379067f
+
+static void build_lights(const float *vtx, const int32_t *idx, uint32_t n_tri,
+                         const os_material *mats, const int32_t *mat_ids, os_lights *L)
+{
+    L->tri = (int32_t *)malloc(sizeof(int32_t) * (n_tri ? n_tri : 1));
+    L->cdf = (float *)malloc(sizeof(float) * (n_tri ? n_tri : 1));
+    L->count = 0;
+    float total = 0.0f;
+    for (uint32_t t = 0; t < n_tri; ++t) {
+        const os_material *m = &mats[mat_ids[t]];
+        if (!((m->ke[0] + m->ke[1]) + m->ke[2] > 0.0f)) continue;
+        const float *a = vtx + 3 * (size_t)idx[3 * (size_t)t + 0];
+        const float *b = vtx + 3 * (size_t)idx[3 * (size_t)t + 1];
+        const float *c = vtx + 3 * (size_t)idx[3 * (size_t)t + 2];
+        const v3 n = cross(sub(V(b[0], b[1], b[2]), V(a[0], a[1], a[2])),
+                           sub(V(c[0], c[1], c[2]), V(a[0], a[1], a[2])));
+        const float len2 = dot(n, n);
+        if (!(len2 > 0.0f)) continue;
+        total += 0.5f * sqrtf(len2);
+        L->tri[L->count] = (int32_t)t;
+        L->cdf[L->count] = total;
+        ++L->count;
+    }
+    L->area = total;
+}
+
+static uint32_t cdf_find(const float *cdf, uint32_t n, float x)
+{
+    uint32_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] > x) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+static float mis_weight(float mine, float other)
+{
+    const float r = other / mine;
+    return 1.0f / (1.0f + r * r);
+}
+
+/* What next-event estimation at a vertex produced. */
+typedef struct { int shadow; v3 so, sd, direct; float smax; } os_nee;
 
 /* One path vertex; returns 1 if the path continues (then *thr, *no, *nd are updated). */
 static int shade_vertex(const os_material *m, v3 v0, v3 v1, v3 v2, float b0, float b1, float b2,
                         v3 rd, v3 *thr, uint32_t key, uint32_t bounce, const os_params *P,
-                        v3 *emitted, v3 *no, v3 *nd)
+                        v3 *emitted, v3 *no, v3 *nd, const os_lights *lights, const float *vtx,
+                        const int32_t *idx, const os_material *mats, const int32_t *mat_ids,
+                        float *q_io, float t_hit, os_nee *nee)
 {
+    const float q_in = *q_io;
+    *q_io = -1.0f;
+    nee->shadow = 0;
     const v3 ke = V(m->ke[0], m->ke[1], m->ke[2]);
     *emitted = mul(*thr, ke);
+    v3 ng = cross(sub(v1, v0), sub(v2, v0));
+    const float len2 = dot(ng, ng);
+    const int use_nee = (P->flags & OS_FLAG_NEE) && lights->count > 0;
+    if (use_nee && q_in > 0.0f && (ke.x + ke.y) + ke.z > 0.0f && len2 > 0.0f) {
+        const float cos_l = fabsf(dot(ng, rd)) / sqrtf(len2);
+        if (cos_l > 0.0f) {
+            const float pl = (t_hit * t_hit) / (cos_l * lights->area);
+            *emitted = scale(*emitted, mis_weight(q_in, pl));
+        }
+    }
     if (bounce + 1 >= P->max_depth) return 0;
 
     const v3 p = comb3(v0, b0, v1, b1, v2, b2);
-    v3 ng = cross(sub(v1, v0), sub(v2, v0));
-    const float len2 = dot(ng, ng);
     if (!(len2 > 0.0f)) return 0;
     ng = divs(ng, sqrtf(len2));
     const v3 n = dot(ng, rd) > 0.0f ? V(-ng.x, -ng.y, -ng.z) : ng;
@@ -156,6 +222,71 @@ static int shade_vertex(const os_material *m, v3 v0, v3 v1, v3 v2, float b0, flo
     if (!(wsum > 0.0f)) return 0;
     const float p_spec = ws / wsum;
     const uint32_t dim0 = 2u + bounce * (uint32_t)DIMS_PER_BOUNCE;
+    const float rough = fminf(fmaxf(m->roughness, 0.03f), 1.0f);
+    const float alpha = rough * rough;
+    const float a2 = alpha * alpha;
+    const float big = fmaxf(1.0f, fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
+    const float offs = P->ray_offset * big;
+    const v3 org = V(p.x + n.x * offs, p.y + n.y * offs, p.z + n.z * offs);
+
+    if (use_nee) {
+        const float u_sel = rnd(key, dim0 + DIM_LSEL);
+        const float ua = rnd(key, dim0 + DIM_L1);
+        const float ub = rnd(key, dim0 + DIM_L2);
+        const uint32_t li = cdf_find(lights->cdf, lights->count, u_sel * lights->area);
+        const int32_t lt = lights->tri[li];
+        const float *q0 = vtx + 3 * (size_t)idx[3 * (size_t)lt + 0];
+        const float *q1 = vtx + 3 * (size_t)idx[3 * (size_t)lt + 1];
+        const float *q2 = vtx + 3 * (size_t)idx[3 * (size_t)lt + 2];
+        const v3 l0 = V(q0[0], q0[1], q0[2]), l1 = V(q1[0], q1[1], q1[2]), l2 = V(q2[0], q2[1], q2[2]);
+        const float su = sqrtf(ua);
+        const float c0 = 1.0f - su, c1 = ub * su;
+        const float c2 = (1.0f - c0) - c1;
+        const v3 y = comb3(l0, c0, l1, c1, l2, c2);
+        const v3 dv = sub(y, org);
+        const float dist2 = dot(dv, dv);
+        const v3 lc = cross(sub(l1, l0), sub(l2, l0));
+        const float ll2 = dot(lc, lc);
+        if (dist2 > 0.0f && ll2 > 0.0f) {
+            const float dist = sqrtf(dist2);
+            const v3 wi = divs(dv, dist);
+            const float n_wi = dot(n, wi);
+            const float cos_l = fabsf(dot(lc, wi)) / sqrtf(ll2);
+            const float pl = dist2 / (cos_l * lights->area);
+            if (n_wi > 0.0f && cos_l > 0.0f && pl > 0.0f) {
+                const os_material *lm = &mats[mat_ids[lt]];
+                const float qd = (1.0f - p_spec) * (n_wi * OS_INV_PI);
+                v3 f = scale(kd, (n_wi * OS_INV_PI) * mis_weight(pl, qd));
+                const v3 hv = V(wo.x + wi.x, wo.y + wi.y, wo.z + wi.z);
+                const float hl2 = dot(hv, hv);
+                if (ws > 0.0f && hl2 > 0.0f) {
+                    const v3 h = divs(hv, sqrtf(hl2));
+                    const float n_h = dot(n, h), wo_h = dot(wo, h);
+                    if (n_h > 0.0f && wo_h > 0.0f) {
+                        const float tt = (n_h * n_h) * (a2 - 1.0f) + 1.0f;
+                        const float D = (a2 * OS_INV_PI) / (tt * tt);
+                        const float om = 1.0f - wo_h;
+                        const float om2 = om * om;
+                        const float om5 = (om2 * om2) * om;
+                        const v3 F = V(ks.x + (1.0f - ks.x) * om5, ks.y + (1.0f - ks.y) * om5,
+                                       ks.z + (1.0f - ks.z) * om5);
+                        const float g1o = (2.0f * n_wo) / (n_wo + sqrtf(a2 + (1.0f - a2) * (n_wo * n_wo)));
+                        const float g1i = (2.0f * n_wi) / (n_wi + sqrtf(a2 + (1.0f - a2) * (n_wi * n_wi)));
+                        const float qs = p_spec * ((D * n_h) / (4.0f * wo_h));
+                        const float fs = (((D * g1o) * g1i) / (4.0f * n_wo)) * mis_weight(pl, qs);
+                        f = V(f.x + F.x * fs, f.y + F.y * fs, f.z + F.z * fs);
+                    }
+                }
+                const v3 le = V(lm->ke[0], lm->ke[1], lm->ke[2]);
+                nee->direct = divs(mul(mul(*thr, f), le), pl);
+                nee->shadow = max3(nee->direct) > 0.0f;
+                nee->so = org;
+                nee->sd = wi;
+                nee->smax = dist * 0.999f - 2e-4f;
+            }
+        }
+    }
+
     const float u_lobe = rnd(key, dim0 + DIM_LOBE);
     const float u1 = rnd(key, dim0 + DIM_U1);
     const float u2 = rnd(key, dim0 + DIM_U2);
@@ -165,10 +296,8 @@ static int shade_vertex(const os_material *m, v3 v0, v3 v1, v3 v2, float b0, flo
     basis(n, &t, &b);
 
     v3 wi, weight;
+    float q;
     if (u_lobe < p_spec) {
-        const float rough = fminf(fmaxf(m->roughness, 0.03f), 1.0f);
-        const float alpha = rough * rough;
-        const float a2 = alpha * alpha;
         const float cos2 = (1.0f - u1) / (1.0f + (a2 - 1.0f) * u1);
         const float cos_h = sqrtf(cos2);
         const float sin_h = sqrtf(fmaxf(0.0f, 1.0f - cos2));
@@ -188,29 +317,32 @@ static int shade_vertex(const os_material *m, v3 v0, v3 v1, v3 v2, float b0, flo
         const float g1i = (2.0f * n_wi) / (n_wi + sqrtf(a2 + (1.0f - a2) * (n_wi * n_wi)));
         const float w = ((g1o * g1i) * wo_h) / ((n_wo * n_h) * p_spec);
         weight = scale(F, w);
+        const float tt = (n_h * n_h) * (a2 - 1.0f) + 1.0f;
+        const float D = (a2 * OS_INV_PI) / (tt * tt);
+        q = p_spec * ((D * n_h) / (4.0f * wo_h));
     } else {
         const float rr = sqrtf(u1);
         const float z = sqrtf(fmaxf(0.0f, 1.0f - u1));
         wi = comb3(t, rr * cphi, b, rr * sphi, n, z);
         weight = divs(kd, 1.0f - p_spec);
+        q = (1.0f - p_spec) * (z * OS_INV_PI);
     }
     v3 nthr = mul(*thr, weight);
 
     if (bounce >= P->rr_start_depth) {
-        const float q = fminf(max3(nthr), 0.95f);
+        const float qq = fminf(max3(nthr), 0.95f);
         const float u_rr = rnd(key, dim0 + DIM_RR);
-        if (!(u_rr < q)) return 0;
-        nthr = divs(nthr, q);
+        if (!(u_rr < qq)) return 0;
+        nthr = divs(nthr, qq);
     }
     if (!(max3(nthr) > 0.0f)) return 0;
 
     const float wl = sqrtf(dot(wi, wi));
     if (!(wl > 0.0f)) return 0;
-    const float big = fmaxf(1.0f, fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
-    const float offs = P->ray_offset * big;
-    *no = V(p.x + n.x * offs, p.y + n.y * offs, p.z + n.z * offs);
+    *no = org;
     *nd = divs(wi, wl);
     *thr = nthr;
+    *q_io = q > 0.0f ? q : -1.0f;
     return 1;
 }
 
@@ -254,7 +386,7 @@ static void camera_ray(const os_camera *cam, uint32_t width, uint32_t height, fl
 static v3 trace_path(const o_bbox *nodes, const float *vtx, const int32_t *idx,
                      const os_material *mats, const int32_t *mat_ids, const os_camera *cam,
                      const os_params *P, uint32_t x, uint32_t y, uint32_t sample,
-                     uint64_t *rays_traced)
+                     uint64_t *rays_traced, const os_lights *lights)
 {
     const uint32_t key = path_key(P->seed, y * P->width + x, sample);
     float jx = 0.5f, jy = 0.5f;
@@ -265,6 +397,7 @@ static v3 trace_path(const o_bbox *nodes, const float *vtx, const int32_t *idx,
     o_ray ray;
     camera_ray(cam, P->width, P->height, (float)x + jx, (float)y + jy, &ray);
     v3 thr = V(1.0f, 1.0f, 1.0f), L = V(0.0f, 0.0f, 0.0f);
+    float q = -1.0f;
     for (uint32_t bounce = 0; bounce < P->max_depth; ++bounce) {
         o_isect h;
         o_intersect_scene_closest(nodes, vtx, idx, &ray, &h, NULL);
@@ -279,14 +412,31 @@ static v3 trace_path(const o_bbox *nodes, const float *vtx, const int32_t *idx,
         const float *p0 = vtx + 3 * (int64_t)t[0], *p1 = vtx + 3 * (int64_t)t[1],
                     *p2 = vtx + 3 * (int64_t)t[2];
         v3 emitted, no, nd;
+        os_nee nee;
         const int alive = shade_vertex(&mats[mat_ids[h.primid]], V(p0[0], p0[1], p0[2]),
                                        V(p1[0], p1[1], p1[2]), V(p2[0], p2[1], p2[2]),
                                        h.uvwt[0], h.uvwt[1], h.uvwt[2],
                                        V(ray.d[0], ray.d[1], ray.d[2]), &thr, key, bounce, P,
-                                       &emitted, &no, &nd);
+                                       &emitted, &no, &nd, lights, vtx, idx, mats, mat_ids, &q,
+                                       h.uvwt[3], &nee);
         L.x += emitted.x;
         L.y += emitted.y;
         L.z += emitted.z;
+        if (nee.shadow) {
+            int occluded = 0;
+            if (nee.smax > 0.0f) {
+                o_ray sr;
+                sr.o[0] = nee.so.x; sr.o[1] = nee.so.y; sr.o[2] = nee.so.z; sr.o[3] = nee.smax;
+                sr.d[0] = nee.sd.x; sr.d[1] = nee.sd.y; sr.d[2] = nee.sd.z; sr.d[3] = 0.0f;
+                occluded = o_intersect_scene_any(nodes, vtx, idx, &sr);   /* bvh.glslh:378-414 */
+                ++*rays_traced;
+            }
+            if (!occluded) {
+                L.x += nee.direct.x;
+                L.y += nee.direct.y;
+                L.z += nee.direct.z;
+            }
+        }
         if (!alive) break;
         ray.o[0] = no.x; ray.o[1] = no.y; ray.o[2] = no.z; ray.o[3] = 1e30f;
         ray.d[0] = nd.x; ray.d[1] = nd.y; ray.d[2] = nd.z; ray.d[3] = 0.0f;
@@ -301,10 +451,13 @@ static v3 trace_path(const o_bbox *nodes, const float *vtx, const int32_t *idx,
 uint64_t os_render(const o_bbox *nodes, const float *vtx, const int32_t *idx,
                    const os_material *mats, const int32_t *mat_ids, const os_camera *cam,
                    const os_params *P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
-                   float *film, int nthreads)
+                   float *film, int nthreads, uint32_t n_tri)
 {
     uint64_t rays = 0;
     if (nthreads < 1) nthreads = 1;
+    os_lights lights = { NULL, NULL, 0, 0.0f };
+    if (P->flags & OS_FLAG_NEE) build_lights(vtx, idx, n_tri, mats, mat_ids, &lights);
+    const os_lights *LP = &lights;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+ : rays)
     for (int64_t y = y0; y < (int64_t)y1; ++y) {
         for (uint32_t x = x0; x < x1; ++x) {
@@ -320,7 +473,7 @@ uint64_t os_render(const o_bbox *nodes, const float *vtx, const int32_t *idx,
             }
             for (uint32_t s = 0; s < P->sample_count; ++s) {
                 const v3 L = trace_path(nodes, vtx, idx, mats, mat_ids, cam, P, x, (uint32_t)y,
-                                        P->sample_begin + s, &rays);
+                                        P->sample_begin + s, &rays, LP);
                 f[0] += L.x;
                 f[1] += L.y;
                 f[2] += L.z;
@@ -328,6 +481,8 @@ uint64_t os_render(const o_bbox *nodes, const float *vtx, const int32_t *idx,
             }
         }
     }
+    free(lights.tri);
+    free(lights.cdf);
     return rays;
 }
 

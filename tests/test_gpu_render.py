@@ -37,10 +37,11 @@ def _compare(mipt, oracle, ctx, scene, cam, W, H, exact=True, **kw):
         err = rel_rmse(got[..., :3], want[..., :3])
         assert err <= REL_RMSE_TOL, f"relative RMSE {err}"
         np.testing.assert_array_equal(got[..., 3], want[..., 3])
-        assert st.rays_primary + st.rays_bounce == rays
+        assert st.rays_primary + st.rays_bounce + st.rays_shadow == rays
         n_diff = int((got.view(np.uint32) != want.view(np.uint32)).sum())
         print(f"rel-RMSE {err:.3e}, {n_diff} differing words of {got.size}, "
-              f"{st.rays_primary} primary + {st.rays_bounce} bounce rays, {st.tie_rays} ties")
+              f"{st.rays_primary} primary + {st.rays_bounce} bounce + {st.rays_shadow} shadow rays, "
+              f"{st.tie_rays} ties")
         if exact:
             assert n_diff == 0, f"film differs from the CPU restatement in {n_diff} words"
         return got, st
@@ -79,6 +80,26 @@ def test_atrium_lambert_ggx_depth8(mipt, oracle, scenes, gpu_ctx):
     got, st = _compare(mipt, oracle, gpu_ctx, scene, cam, 160, 90, sample_count=4, max_depth=8,
                        seed=42, background=(0.3, 0.35, 0.4))
     assert st.rays_bounce > 2 * st.rays_primary
+
+
+def test_cornell_next_event_estimation(mipt, oracle, scenes, gpu_ctx):
+    """Shadow rays (IntersectSceneAny over the two-child nodes) + MIS: same film as the CPU
+    restatement, which walks the skip links for its shadow rays."""
+    got, st = _compare(mipt, oracle, gpu_ctx, scenes.cornell_box(), cornell_camera(mipt), 96, 96,
+                       sample_count=8, max_depth=4, seed=3, flags=mipt.PT_RENDER_NEE)
+    assert st.rays_shadow > 0.5 * st.rays_primary
+    plain, _ = _compare(mipt, oracle, gpu_ctx, scenes.cornell_box(), cornell_camera(mipt), 96, 96,
+                        sample_count=8, max_depth=4, seed=3)
+    a, b = got[..., :3].mean() / 8, plain[..., :3].mean() / 8
+    assert abs(a - b) / b < 0.15            # two estimators of one image (8 spp: loose)
+
+
+def test_atrium_next_event_estimation(mipt, oracle, scenes, gpu_ctx):
+    scene = scenes.atrium(65536, seed=42)
+    cam = scenes.atrium_camera(160 / 90)
+    _, st = _compare(mipt, oracle, gpu_ctx, scene, cam, 160, 90, sample_count=2, max_depth=5,
+                     seed=7, background=(0.3, 0.35, 0.4), flags=mipt.PT_RENDER_NEE)
+    assert st.rays_shadow > 0
 
 
 def test_furnace_on_gpu(mipt, oracle, scenes, gpu_ctx):
@@ -161,8 +182,8 @@ def test_film_wrap_and_errors(mipt, scenes, gpu_ctx):
             mipt.render(gpu_ctx, sc, cam, mipt.render_params(16, 8, max_depth=0), film)
         with pytest.raises(mipt.MiptError, match="tile_size"):
             mipt.render(gpu_ctx, sc, cam, mipt.render_params(16, 8, tile_size=12), film)
-        with pytest.raises(mipt.MiptError, match="not implemented"):
-            mipt.render(gpu_ctx, sc, cam, mipt.render_params(16, 8, flags=mipt.PT_RENDER_NEE), film)
+        # next-event estimation in a scene without emitters is a no-op, not an error
+        mipt.render(gpu_ctx, sc, cam, mipt.render_params(16, 8, flags=mipt.PT_RENDER_NEE), film)
         film.close()
     finally:
         sc.close()

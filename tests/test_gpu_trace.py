@@ -159,9 +159,15 @@ def test_moller_trumbore_mode_and_any_hit(mipt, oracle, scenes, gpu_ctx):
         got = sc.trace_closest(rays, mipt.PT_TRACE_MOLLER_TRUMBORE)
         want = oracle.closest(nodes, vtx, idx, rays, nthreads=8, moller_trumbore=True)
         assert len(same_hits(got, want)) == 0
-        occ = sc.trace_any(rays)
-        np.testing.assert_array_equal(occ, oracle.any_hit(nodes, vtx, idx, rays, nthreads=8))
+        want_occ = oracle.any_hit(nodes, vtx, idx, rays, nthreads=8)
+        occ = sc.trace_any(rays)                                 # two-child nodes, near child first
+        np.testing.assert_array_equal(occ, want_occ)
         assert 0.05 < occ.mean() < 0.95
+        gpu_ctx.set_option("any.exact_order", 1)                 # the reference's skip-link walk
+        try:
+            np.testing.assert_array_equal(sc.trace_any(rays), want_occ)
+        finally:
+            gpu_ctx.set_option("any.exact_order", 0)
     finally:
         sc.close()
 

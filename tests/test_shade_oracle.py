@@ -95,5 +95,39 @@ def test_cornell_energy_is_sane(oracle, mipt, scenes):
     assert np.isfinite(img).all() and img.min() >= 0
     assert 0.02 < img.mean() < 2.0
     # the left wall is red, the right wall green (as seen from the original camera)
-    left, right = img[24, 7], img[24, 40]
+    left, right = img[16:32, 5:10].mean(axis=(0, 1)), img[16:32, 38:43].mean(axis=(0, 1))
     assert left[0] > 2 * left[1] and right[1] > 2 * right[0]
+
+
+def test_next_event_estimation_is_unbiased_and_quieter(oracle, mipt, scenes):
+    """Light sampling + MIS estimates the same image as plain path tracing, with less noise:
+    Cornell box, two seeds each way."""
+    cam = mipt.look_at_camera((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), fovy_deg=39.3)
+    out = {}
+    for flags in (0, mipt.PT_RENDER_NEE):
+        imgs = []
+        for seed in (1, 2):
+            film, rays, _ = _render(oracle, mipt, scenes.cornell_box(), cam, width=40, height=40,
+                                    sample_count=48, max_depth=4, seed=seed, flags=flags)
+            imgs.append(film[..., :3] / film[..., 3:])
+        out[flags] = (np.mean(imgs), imgs, rays)
+    plain, nee = out[0], out[mipt.PT_RENDER_NEE]
+    assert abs(nee[0] - plain[0]) / plain[0] < 0.03
+    # noise = difference between the two seeds, away from the directly seen lamp (whose
+    # jittered edge is equally noisy both ways)
+    dim = np.max(plain[1] + nee[1], axis=(0, 3)) < 1.0
+    noise = [float(np.sqrt(np.mean((i[0] - i[1])[dim] ** 2))) for i in (plain[1], nee[1])]
+    assert noise[1] < 0.5 * noise[0], noise
+    assert nee[2] > plain[2]                 # shadow rays are counted
+
+
+def test_next_event_estimation_furnace(oracle, mipt, scenes):
+    """Every surface emits 1 with albedo 1/2: light sampling and MIS weights must still add
+    up to sum_{k<depth} 2^-k in expectation."""
+    cam = mipt.look_at_camera((0.1, 0.2, -0.3), (0.5, 0.3, 1.0), fovy_deg=70.0)
+    film, _, _ = _render(oracle, mipt, _box_scene(scenes, (0.5, 0.5, 0.5), (1, 1, 1)), cam,
+                         width=32, height=32, sample_count=32, max_depth=4, rr_start_depth=99,
+                         flags=mipt.PT_RENDER_NEE)
+    want = sum(0.5 ** k for k in range(4))
+    mean = (film[..., :3] / film[..., 3:]).mean()
+    assert abs(mean - want) / want < 0.01
