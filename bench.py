@@ -44,6 +44,8 @@ def parse_args():
                     help="how N ranks split the frame (N > 1)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=INT",
                     help="pt_context_set_option tuning knob, e.g. extend.persistent=0")
+    ap.add_argument("--nee", action="store_true",
+                    help="next-event estimation: one shadow ray per path vertex (counted in value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-scale", type=int, default=2,
                     help="the CPU baseline renders the frame at 1/scale resolution in x and y")
@@ -88,7 +90,10 @@ def main():
 
     from mipt import distributed as D
 
+    base_flags = mipt.PT_RENDER_NEE if args.nee else 0
+
     def params(step, flags=0):
+        flags |= base_flags
         common = dict(max_depth=args.depth, seed=42, rr_start_depth=3, background=sky, flags=flags)
         if args.sharding == "tiles":
             # rank r renders the tiles it owns with world*spp samples: same work per rank
@@ -110,7 +115,7 @@ def main():
 
     # ---- work per ray (untimed): the same kernels with their test counters compiled in ------
     st = mipt.render(ctx, scene, cam, params(0, mipt.PT_RENDER_COUNT_WORK), film, stats=True)
-    rays0 = st.rays_primary + st.rays_bounce
+    rays0 = st.rays_primary + st.rays_bounce          # the counters cover the closest-hit kernel only
     n_box, n_tri = st.box_tests / rays0, st.tri_tests / rays0
     bytes_per_ray = 32.0 * n_box + 48.0 * n_tri + 64.0        # reference-layout bytes per ray
     film.clear()
@@ -124,11 +129,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rays = paths = ties = launches = 0
+    rays = paths = ties = launches = shadow = 0
     extend_ms = 0.0
     for k in range(args.steps):
         st = mipt.render(ctx, scene, cam, params(k), film, stats=True)
         rays += st.rays_primary + st.rays_bounce
+        shadow += st.rays_shadow
         paths += st.paths
         ties += st.tie_rays
         launches += st.extend_launches
@@ -140,7 +146,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    agg = torch.tensor([elapsed, float(rays), float(paths)], dtype=torch.float64, device="cuda")
+    agg = torch.tensor([elapsed, float(rays + shadow), float(paths)], dtype=torch.float64, device="cuda")
     if world > 1:
         mx = agg.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -152,7 +158,7 @@ def main():
         img = film_t[..., :3] / film_t[..., 3:].clamp(min=1)
         achieved = bytes_per_ray * rays / (extend_ms * 1e-3) / 1e9
         out = {
-            "metric": "Mrays/s (primary+bounce), Sponza 1080p depth 8",
+            "metric": "Mrays/s (primary+bounce%s), Sponza 1080p depth 8" % ("+shadow" if args.nee else ""),
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -164,7 +170,9 @@ def main():
                                    "Lambert+GGX, max depth %d, %d spp per step per GPU; full "
                                    "wavefront path tracer (raygen, extend, shade, accumulate)"
                                    % (args.tris, W, H, args.depth, spp),
-                       "rays_per_step_per_gpu": rays / args.steps,
+                       "rays_per_step_per_gpu": (rays + shadow) / args.steps,
+                       "shadow_rays_per_step_per_gpu": shadow / args.steps,
+                       "next_event_estimation": bool(args.nee),
                        "samples_per_pixel_total": args.steps * spp * world,
                        "bvh_build_s": round(build_s, 3),
                        "sharding": ("sample ranges per rank, RCCL reduce of the film at the end"
@@ -174,7 +182,7 @@ def main():
             "tie_rays": int(ties), "mean_radiance": float(img.mean().item()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
-                         "kernel": "k_pt_extend", "launches": int(launches),
+                         "kernel": "k_pt_extend_persistent<false>", "launches": int(launches),
                          "avg_launch_ms": extend_ms / max(launches, 1),
                          "kernel_time_share": extend_ms * 1e-3 / elapsed,
                          "note": "algorithmic reference-layout bytes; the 34 MB scene is cache "
@@ -184,7 +192,7 @@ def main():
         # benchmark cannot read on itself: they are taken from the committed rocprofv3 --pmc
         # passes over this same command (profiles/collect_traffic.sh) when the workload matches.
         tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
-        default_workload = (args.tris, W, H, args.depth, spp) == (262144, 1920, 1080, 8, 4)
+        default_workload = (args.tris, W, H, args.depth, spp, args.nee) == (262144, 1920, 1080, 8, 4, False)
         if os.path.exists(tpath) and default_workload and world == 1:
             with open(tpath) as f:
                 tr = json.load(f)
@@ -216,7 +224,8 @@ def cpu_baseline(args, nodes, vtx, idx, mats, mids, sky):
     w, h = args.width // s, args.height // s
     cam = scenes.atrium_camera(w / h)
     p = mipt.render_params(w, h, sample_begin=0, sample_count=args.spp_per_step, max_depth=args.depth,
-                           seed=42, rr_start_depth=3, background=sky)
+                           seed=42, rr_start_depth=3, background=sky,
+                           flags=mipt.PT_RENDER_NEE if args.nee else 0)
     t0 = time.perf_counter()
     _, rays = oracle.render(nodes, vtx, idx, mats, mids, cam, p, nthreads=cores)
     dt = time.perf_counter() - t0

@@ -240,6 +240,34 @@ __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro,
     }
 }
 
+// Start of an occlusion query (IntersectSceneAny, shaders/RadeonRays/bvh.glslh:378-414) in
+// the same state machine: 1/d as at :380, the culling distance stays at r.o.w, and the shear
+// slots of the ray, which the Moller-Trumbore test has no use for, carry the direction.
+// exact: leave the ray to the skip-link walk (see occluded_wide for when that is needed).
+__device__ __forceinline__ void any_begin(OrderedState &st, const float4 ro, const float4 rd,
+                                          int32_t *stack, bool exact) {
+    st.r.ox = ro.x; st.r.oy = ro.y; st.r.oz = ro.z;
+    st.r.ix = 1.0f / rd.x; st.r.iy = 1.0f / rd.y; st.r.iz = 1.0f / rd.z;
+    st.r.sx = rd.x; st.r.sy = rd.y; st.r.sz = rd.z;
+    st.r.axis = 2;
+    st.tmax = ro.w;
+    st.bound = ro.w;
+    st.tbest = ro.w;
+    st.second = INFINITY;
+    st.b0 = 0.f; st.b1 = 0.f; st.b2 = 0.f;
+    st.primid = -1;                // >= 0 once an occluder has been found
+    st.tie = false;
+    stack[0] = kSentinel;
+    st.sp = 1;
+    st.cur = 0;
+    const float chk = ((ro.x + ro.y) + (ro.z + rd.x)) + (rd.y + rd.z);
+    if (exact || !(fabsf(chk) < INFINITY) || !(ro.w == ro.w) ||
+        (rd.x == 0.f && rd.y == 0.f && rd.z == 0.f)) {
+        st.tie = true;
+        st.cur = kSentinel;
+    }
+}
+
 // Advances the traversing lanes of the wave until at most `min_active` of them are still
 // traversing (0: run the wave's rays to completion).  Each round the wave votes on one step:
 // the lanes standing at a triangle take a triangle step once `leaf_lanes` of them have
@@ -248,7 +276,9 @@ __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro,
 // Stack slot 0 holds kSentinel (ordered_begin puts it there), so a pop needs no emptiness
 // test: popping the bottom entry ends the ray.  Both steps are written with selects; the
 // only divergent regions are the stack accesses and the work inside the triangle test.
-template <bool COUNT>
+// ANY: occlusion query -- the triangle step is the Moller-Trumbore test of
+// shaders/RadeonRays/bvh.glslh:289-310 and the first hit ends the ray.
+template <bool COUNT, bool ANY = false>
 __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedState &st,
                                                 int32_t *stack, int min_active, int leaf_lanes,
                                                 unsigned long long &nb, unsigned long long &nt) {
@@ -292,6 +322,19 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
 #else
             if (COUNT) ++nt;
 #endif
+            if (ANY) {
+                float m1, m2, temp;
+                moller_trumbore(st.r.ox, st.r.oy, st.r.oz, st.r.sx, st.r.sy, st.r.sz, q0.x, q0.y,
+                                q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, m1, m2, temp);
+                const bool hit = !((m1 < -PT_MT_EPS) | (m1 > 1.f + PT_MT_EPS) | (m2 < -PT_MT_EPS) |
+                                   (m1 + m2 > 1.f + PT_MT_EPS) | (temp < -PT_MT_EPS) |
+                                   (temp > st.tmax + PT_MT_EPS));               // :301
+                st.primid = hit ? 0 : st.primid;
+                --st.sp;
+                const int32_t popped = stack[st.sp * kTraceBlock];
+                st.cur = hit ? kSentinel : popped;
+                continue;
+            }
             float h0 = 0.f, h1 = 0.f, h2 = 0.f, ht = 0.f;
             const bool hit = intersect_triangle_watertight(st.r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y,
                                                            q1.z, q1.w, q2.x, st.bound, h0, h1, h2, ht);
@@ -444,18 +487,28 @@ __device__ __forceinline__ void count_ties(bool tie, unsigned int *tie_count) {
         atomicAdd(tie_count, (unsigned int)__popcll(m));
 }
 
-// Closest hits of rays[0..n) by persistent waves: the grid is sized to the machine, not to
-// the queue.  Chunks of 64 rays are dealt round-robin to the waves (chunk c belongs to wave
-// c % n_waves: static, so no work-distribution atomics), and a wave tops its idle lanes up
-// from its own stream whenever `refill` or more of them have finished, instead of idling
-// them until its slowest ray ends.  Every wave reaches the end of its finite stream, so the
-// grid always drains.
-template <bool COUNT>
-__device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, const pt_ray *rays,
-                                                        pt_hit *hits, uint32_t n, bool fixup,
-                                                        int refill, int leaf_lanes, int32_t *stack,
-                                                        unsigned int *tie_count,
-                                                        DeviceTraceCounters *work) {
+// Where the persistent closest-hit loop puts a finished ray.
+struct HitSink {
+    pt_hit *hits;
+    __device__ __forceinline__ void operator()(uint32_t ray, int32_t shapeid, int32_t primid,
+                                               float b0, float b1, float b2, float t) const {
+        store_hit(hits, ray, shapeid, primid, b0, b1, b2, t);
+    }
+};
+
+// Rays[0..n) by persistent waves: the grid is sized to the machine, not to the queue.
+// Chunks of 64 rays are dealt round-robin to the waves (chunk c belongs to wave c % n_waves:
+// static, so no work-distribution atomics), and a wave tops its idle lanes up from its own
+// stream whenever `refill` or more of them have finished, instead of idling them until its
+// slowest ray ends.  Every wave reaches the end of its finite stream, so the grid always
+// drains.  ANY = false: closest hits, sink(ray, shapeid, primid, b0, b1, b2, t).
+// ANY = true: occlusion queries, sink(ray, occluded).
+template <bool COUNT, bool ANY, class Sink>
+__device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const pt_ray *rays,
+                                                    uint32_t n, bool fixup, int refill,
+                                                    int leaf_lanes, int32_t *stack,
+                                                    unsigned int *tie_count,
+                                                    DeviceTraceCounters *work, Sink sink) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (kTraceBlock / 64) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (kTraceBlock / 64);
@@ -473,20 +526,31 @@ __device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, co
     st.tbest = 0.f;
     unsigned long long nb = 0, nt = 0;
     unsigned int n_ties = 0;
+    const bool any_exact = s.n_tri < 2;         // see occluded_wide
     for (;;) {
         if (my_ray != kNone && st.cur == kSentinel) {          // retire a finished ray
-            int32_t shapeid = st.primid >= 0 ? 0 : -1, primid = st.primid;
-            float b0 = st.b0, b1 = st.b1, b2 = st.b2, t = st.tbest;
-            if (ordered_is_tie(st)) {
-                ++n_ties;
+            if constexpr (ANY) {
+                bool occ = st.primid >= 0;
+                if (st.tie) {
+                    const float4 ro = reinterpret_cast<const float4 *>(rays + my_ray)[0];
+                    const float4 rd = reinterpret_cast<const float4 *>(rays + my_ray)[1];
+                    occ = occluded_skiplink(s, ro, rd);
+                }
+                sink(my_ray, occ);
+            } else {
+                int32_t shapeid = st.primid >= 0 ? 0 : -1, primid = st.primid;
+                float b0 = st.b0, b1 = st.b1, b2 = st.b2, t = st.tbest;
+                if (ordered_is_tie(st)) {
+                    ++n_ties;
+                }
+                if (fixup && ordered_is_tie(st)) {
+                    unsigned long long xb = 0, xt = 0;
+                    const float4 ro = reinterpret_cast<const float4 *>(rays + my_ray)[0];
+                    const float4 rd = reinterpret_cast<const float4 *>(rays + my_ray)[1];
+                    traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt);
+                }
+                sink(my_ray, shapeid, primid, b0, b1, b2, t);
             }
-            if (fixup && ordered_is_tie(st)) {
-                unsigned long long xb = 0, xt = 0;
-                const float4 ro = reinterpret_cast<const float4 *>(rays + my_ray)[0];
-                const float4 rd = reinterpret_cast<const float4 *>(rays + my_ray)[1];
-                traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt);
-            }
-            store_hit(hits, my_ray, shapeid, primid, b0, b1, b2, t);
             my_ray = kNone;
         }
         const bool idle = my_ray == kNone;
@@ -498,7 +562,8 @@ __device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, co
                 if (idx < n) {
                     const float4 ro = reinterpret_cast<const float4 *>(rays + idx)[0];
                     const float4 rd = reinterpret_cast<const float4 *>(rays + idx)[1];
-                    ordered_begin(st, ro, rd, stack);
+                    if constexpr (ANY) any_begin(st, ro, rd, stack, any_exact);
+                    else ordered_begin(st, ro, rd, stack);
                     my_ray = idx;
                 }
             }
@@ -508,9 +573,9 @@ __device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, co
             if (pos >= stream_len) break;
             continue;                                           // tail positions past the queue end
         }
-        ordered_advance<COUNT>(s, st, stack, pos < stream_len ? 64 - refill : 0, leaf_lanes, nb, nt);
+        ordered_advance<COUNT, ANY>(s, st, stack, pos < stream_len ? 64 - refill : 0, leaf_lanes, nb, nt);
     }
-    if (n_ties) atomicAdd(tie_count, n_ties);
+    if (!ANY && n_ties) atomicAdd(tie_count, n_ties);
     if (COUNT) {
         nb = wave_sum(nb);
         nt = wave_sum(nt);
@@ -519,6 +584,16 @@ __device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, co
             atomicAdd(&work->tri_tests, nt);
         }
     }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, const pt_ray *rays,
+                                                        pt_hit *hits, uint32_t n, bool fixup,
+                                                        int refill, int leaf_lanes, int32_t *stack,
+                                                        unsigned int *tie_count,
+                                                        DeviceTraceCounters *work) {
+    persistent_traverse<COUNT, false>(s, rays, n, fixup, refill, leaf_lanes, stack, tie_count, work,
+                                      HitSink{hits});
 }
 
 // Compacting append to a queue: every lane with `keep` gets a distinct slot.  One atomic

@@ -69,7 +69,8 @@ void launch_pt_shade(hipStream_t st, const DeviceScene &s, const RenderLaunch &r
                      uint32_t bounce);
 // Shadow rays of one bounce: radiance[path] += carried radiance of every unoccluded ray.
 void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspace &ws,
-                       const unsigned int *shadow_count, uint64_t max_rays);
+                       const unsigned int *shadow_count, uint64_t max_rays,
+                       const ExtendConfig &cfg);
 void launch_pt_shade_depth(hipStream_t st, const RenderWorkspace &ws, const unsigned int *count,
                            uint64_t max_rays);
 void launch_pt_accumulate(hipStream_t st, const RenderLaunch &rl, const RenderWorkspace &ws,

@@ -196,6 +196,22 @@ __global__ __launch_bounds__(kWideBlock) void k_pt_shade(DeviceScene s, RenderLa
 // occlude: IntersectSceneAny (shaders/RadeonRays/bvh.glslh:378-414) for the shadow rays of one
 // bounce; a ray that reaches its light adds the radiance it carries to its path.  A path has
 // at most one shadow ray per bounce, so the additions to a path are ordered by the launches.
+struct ShadowSink {
+    const float4 *carry;
+    float4 *radiance;
+    __device__ __forceinline__ void operator()(uint32_t ray, bool occluded) const {
+        if (occluded) return;
+        const float4 c = carry[ray];
+        const uint32_t pid = __float_as_uint(c.w);
+        float4 L = radiance[pid];
+        L.x += c.x;
+        L.y += c.y;
+        L.z += c.z;
+        radiance[pid] = L;
+    }
+};
+
+// One thread per shadow ray.
 __global__ __launch_bounds__(kBlock) void k_pt_occlude(DeviceScene s, RenderWorkspace ws,
                                                        const unsigned int *count, bool wide) {
     __shared__ int32_t s_stack[kTraceStack * kBlock];
@@ -206,15 +222,16 @@ __global__ __launch_bounds__(kBlock) void k_pt_occlude(DeviceScene s, RenderWork
     const float4 rd = reinterpret_cast<const float4 *>(ws.shadow_rays + i)[1];
     const bool occ = wide ? occluded_wide(s, ro, rd, s_stack + threadIdx.x)
                           : occluded_skiplink(s, ro, rd);
-    if (!occ) {
-        const float4 c = ws.shadow_carry[i];
-        const uint32_t pid = __float_as_uint(c.w);
-        float4 L = ws.radiance[pid];
-        L.x += c.x;
-        L.y += c.y;
-        L.z += c.z;
-        ws.radiance[pid] = L;
-    }
+    ShadowSink{ws.shadow_carry, ws.radiance}((uint32_t)i, occ);
+}
+
+// Persistent waves with lane refill and step voting, as the closest-hit kernel.
+__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_persistent(
+    DeviceScene s, RenderWorkspace ws, const unsigned int *count, int refill, int leaf_lanes) {
+    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
+    persistent_traverse<false, true>(s, ws.shadow_rays, *count, true, refill, leaf_lanes,
+                                     s_stack + threadIdx.x, nullptr, nullptr,
+                                     ShadowSink{ws.shadow_carry, ws.radiance});
 }
 
 // PT_RENDER_DEPTH_GREY: the reference's per-pixel output (shaders/depth.frag:90-107).
@@ -313,8 +330,18 @@ void launch_pt_shade(hipStream_t st, const DeviceScene &s, const RenderLaunch &r
 }
 
 void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspace &ws,
-                       const unsigned int *shadow_count, uint64_t max_rays) {
+                       const unsigned int *shadow_count, uint64_t max_rays,
+                       const ExtendConfig &cfg) {
     if (!max_rays) return;
+    if (cfg.persistent_blocks > 0) {
+        static int occ = 0;
+        const unsigned int grid = (unsigned int)std::min<uint64_t>(
+            blocks(max_rays, kBlock),
+            persistent_grid((const void *)k_pt_occlude_persistent, kBlock, cfg, &occ));
+        hipLaunchKernelGGL(k_pt_occlude_persistent, dim3(grid), dim3(kBlock), 0, st, s, ws,
+                           shadow_count, cfg.refill, cfg.leaf_lanes);
+        return;
+    }
     hipLaunchKernelGGL(k_pt_occlude, dim3(blocks(max_rays, kBlock)), dim3(kBlock), 0, st, s, ws,
                        shadow_count, s.n_tri >= 2);
 }

@@ -302,7 +302,7 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
             } else {
                 unsigned int *sc = &c[p.max_depth + 1 + b];
                 launch_pt_shade(st, scene->dev, rl, ws, buf, &c[b], &c[b + 1], sc, paths, b);
-                if (nee && b + 1 < p.max_depth) launch_pt_occlude(st, scene->dev, ws, sc, paths);
+                if (nee && b + 1 < p.max_depth) launch_pt_occlude(st, scene->dev, ws, sc, paths, ecfg);
                 buf ^= 1;
             }
         }
