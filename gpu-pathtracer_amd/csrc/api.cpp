@@ -67,11 +67,6 @@ void DeviceBuffer::release() {
         if (_e != hipSuccess) return hip_fail(_e, #expr);                \
     } while (0)
 
-struct pt_bvh {
-    std::vector<pt_bbox> nodes;
-    uint32_t link_encoding = PT_LINKS_FLOAT_VALUE;
-};
-
 extern "C" {
 
 const char *pt_last_error(void) { return g_last_error.c_str(); }

@@ -67,6 +67,11 @@ struct pt_context {
     }
 };
 
+struct pt_bvh {
+    std::vector<pt_bbox> nodes;
+    uint32_t link_encoding = PT_LINKS_FLOAT_VALUE;
+};
+
 struct pt_film {
     pt_context *ctx = nullptr;
     uint32_t width = 0, height = 0;

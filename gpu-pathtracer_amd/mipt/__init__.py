@@ -25,7 +25,8 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 # ---------------------------------------------------------------- constants
-PT_OK, PT_ERR_INVALID, PT_ERR_DEVICE, PT_ERR_UNSUPPORTED, PT_ERR_IO, PT_ERR_NOMEM = range(6)
+PT_OK, PT_ERR_INVALID, PT_ERR_DEVICE, PT_ERR_UNSUPPORTED, PT_ERR_IO, PT_ERR_NOMEM, PT_ERR_STALE = range(7)
+PT_IMAGE_PPM, PT_IMAGE_PFM = 0, 1
 PT_LINKS_FLOAT_VALUE, PT_LINKS_INT_BITS = 0, 1
 PT_CAMERA_REFERENCE, PT_CAMERA_PINHOLE = 0, 1
 PT_TRACE_DEFAULT, PT_TRACE_EXACT_ORDER, PT_TRACE_MOLLER_TRUMBORE, PT_TRACE_NO_TIE_FIXUP = 0, 1, 2, 4
@@ -138,6 +139,12 @@ _PROTOS = {
     "pt_film_device_ptr": (_vp, [_vp]),
     "pt_film_read": (C.c_int, [_vp, _vp]),
     "pt_film_destroy": (C.c_int, [_vp]),
+    "pt_bvh_cache_key": (C.c_uint64, [_vp, C.c_uint32, _vp]),
+    "pt_bvh_save": (C.c_int, [_vp, C.c_char_p, C.c_uint64]),
+    "pt_bvh_load": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(_vp)]),
+    "pt_film_save": (C.c_int, [_vp, C.c_char_p]),
+    "pt_film_load": (C.c_int, [_vp, C.c_char_p]),
+    "pt_film_write_image": (C.c_int, [_vp, C.c_char_p, C.c_uint32, C.c_float]),
     "pt_shard_layout": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.POINTER(C.c_uint64), _vp]),
     "pt_film_packed_size": (C.c_uint64, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -207,6 +214,36 @@ def build_bvh(leaf_bounds, options: Optional[BvhOptions] = None) -> np.ndarray:
         return np.frombuffer(src, dtype=bbox_dtype).copy()
     finally:
         lib.pt_bvh_destroy(h)
+
+
+def _take_nodes(h) -> np.ndarray:
+    try:
+        n = lib.pt_bvh_node_count(h)
+        src = (C.c_char * (n * 32)).from_address(lib.pt_bvh_nodes(h))
+        return np.frombuffer(src, dtype=bbox_dtype).copy()
+    finally:
+        lib.pt_bvh_destroy(h)
+
+
+def build_bvh_cached(leaf_bounds, path: str, options: Optional[BvhOptions] = None):
+    """Load the BVH of these leaf boxes + options from `path` if it holds one, else build
+    and save it.  Returns (nodes, loaded_from_cache)."""
+    leaf_bounds = _as(leaf_bounds, bbox_dtype, "leaf_bounds")
+    opt = C.byref(options) if options is not None else None
+    key = lib.pt_bvh_cache_key(_ptr(leaf_bounds), leaf_bounds.shape[0], opt)
+    h = _vp()
+    rc = lib.pt_bvh_load(path.encode(), key, C.byref(h))
+    if rc == PT_OK:
+        return _take_nodes(h), True
+    if rc not in (PT_ERR_IO, PT_ERR_STALE):
+        _check(rc)
+    _check(lib.pt_bvh_build(_ptr(leaf_bounds), leaf_bounds.shape[0], opt, C.byref(h)))
+    try:
+        _check(lib.pt_bvh_save(h, path.encode(), key))
+    except MiptError:
+        lib.pt_bvh_destroy(h)
+        raise
+    return _take_nodes(h), False
 
 
 def linearize(bounds, left, right, prim, link_encoding=PT_LINKS_FLOAT_VALUE) -> np.ndarray:
@@ -406,6 +443,16 @@ class Film:
         out = np.empty((self.height, self.width, 4), dtype=np.float32)
         _check(lib.pt_film_read(self._h, _ptr(out)))
         return out
+
+    def save(self, path: str) -> None:
+        """Accumulation checkpoint (sums and sample counts, exact)."""
+        _check(lib.pt_film_save(self._h, path.encode()))
+
+    def load(self, path: str) -> None:
+        _check(lib.pt_film_load(self._h, path.encode()))
+
+    def write_image(self, path: str, fmt: int = PT_IMAGE_PPM, exposure: float = 1.0) -> None:
+        _check(lib.pt_film_write_image(self._h, path.encode(), fmt, exposure))
 
     def packed_size(self, tile_size: int, shard_index: int, shard_count: int) -> int:
         return int(lib.pt_film_packed_size(self._h, tile_size, shard_index, shard_count))

@@ -39,6 +39,7 @@ extern "C" {
 #define PT_ERR_UNSUPPORTED  3
 #define PT_ERR_IO           4
 #define PT_ERR_NOMEM        5
+#define PT_ERR_STALE        6   /* a cache file that was built from other inputs */
 
 /* How leaf payloads and skip links are stored in pmin.w / pmax.w. */
 #define PT_LINKS_FLOAT_VALUE 0u /* float(index), -1.f: what the reference emits
@@ -236,6 +237,23 @@ float *pt_film_device_ptr(pt_film *film);
 /* readback_ssbo, src/main_granite.cpp:499-522: blocking copy to host memory. */
 int pt_film_read(pt_film *film, float *rgba);
 int pt_film_destroy(pt_film *film);
+
+/* Files.  No counterpart in the reference, which rebuilds its BVH at every start
+ * (src/main_granite.cpp:289-293) and keeps no accumulation; the usage pattern is that of its
+ * Vulkan pipeline cache (src/main.cpp:290-315,1187-1196): load if present and valid, else
+ * build and save. */
+/* Key of a build's inputs (leaf boxes + options) for validating a cached BVH. */
+uint64_t pt_bvh_cache_key(const pt_bbox *leaf_bounds, uint32_t n_leaves, const pt_bvh_options *opt);
+int pt_bvh_save(const pt_bvh *bvh, const char *path, uint64_t key);
+/* PT_ERR_IO: unreadable or corrupt; PT_ERR_STALE: intact but saved under another key. */
+int pt_bvh_load(const char *path, uint64_t key, pt_bvh **out);
+/* Accumulation checkpoint: the film's sums and sample counts, exactly (blocking). */
+int pt_film_save(pt_film *film, const char *path);
+int pt_film_load(pt_film *film, const char *path);
+#define PT_IMAGE_PPM 0u   /* 8-bit binary PPM, sRGB transfer curve, clamped */
+#define PT_IMAGE_PFM 1u   /* 32-bit float PFM, linear */
+/* Writes rgb / sample count, scaled by exposure. */
+int pt_film_write_image(pt_film *film, const char *path, uint32_t format, float exposure);
 
 /* Host-only description of a tile sharding: *n_slots = pixel slots of the shard (owned tiles
  * x tile_size^2, the length of its packed buffer); if xy != NULL it receives, per slot, the

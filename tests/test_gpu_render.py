@@ -187,3 +187,42 @@ def test_film_wrap_and_errors(mipt, scenes, gpu_ctx):
         film.close()
     finally:
         sc.close()
+
+
+def test_film_checkpoint_resume_and_image(mipt, scenes, gpu_ctx, tmp_path):
+    """Render 3 samples, checkpoint, restore into a fresh film and render 3 more: the same
+    words as 6 samples in one go.  Then the two image writers."""
+    scene = scenes.cornell_box()
+    cam = cornell_camera(mipt)
+    nodes, sc = _setup(mipt, gpu_ctx, scene)
+    W, H = 64, 48
+    try:
+        full = mipt.Film(gpu_ctx, W, H)
+        mipt.render(gpu_ctx, sc, cam, mipt.render_params(W, H, sample_count=6, max_depth=4), full)
+        a = mipt.Film(gpu_ctx, W, H)
+        mipt.render(gpu_ctx, sc, cam, mipt.render_params(W, H, sample_count=3, max_depth=4), a)
+        ck = str(tmp_path / "film.ckpt")
+        a.save(ck)
+        b = mipt.Film(gpu_ctx, W, H)
+        b.load(ck)
+        mipt.render(gpu_ctx, sc, cam, mipt.render_params(W, H, sample_begin=3, sample_count=3, max_depth=4), b)
+        np.testing.assert_array_equal(b.read().view(np.uint32), full.read().view(np.uint32))
+        with pytest.raises(mipt.MiptError, match="image size"):
+            mipt.Film(gpu_ctx, W, H + 1).load(ck)
+        ppm, pfm = str(tmp_path / "o.ppm"), str(tmp_path / "o.pfm")
+        full.write_image(ppm)
+        full.write_image(pfm, mipt.PT_IMAGE_PFM, exposure=2.0)
+        raw = open(ppm, "rb").read()
+        assert raw.startswith(b"P6\n64 48\n255\n") and len(raw) == 13 + 3 * W * H
+        img = np.frombuffer(raw[13:], dtype=np.uint8).reshape(H, W, 3)
+        assert img.max() == 255 and img.mean() > 5             # the lamp saturates
+        rawf = open(pfm, "rb").read()
+        head = b"PF\n64 48\n-1.0\n"
+        assert rawf.startswith(head)
+        lin = np.frombuffer(rawf[len(head):], dtype=np.float32).reshape(H, W, 3)[::-1]
+        f = full.read()
+        np.testing.assert_allclose(lin, f[..., :3] / f[..., 3:] * 2.0, rtol=1e-6)
+        for x in (full, a, b):
+            x.close()
+    finally:
+        sc.close()

@@ -190,3 +190,28 @@ def test_atrium_stand_in_counts(scenes):
     v2, i2, _, _ = scenes.atrium(65536, seed=42)
     np.testing.assert_array_equal(vtx, v2)
     np.testing.assert_array_equal(idx, i2)
+
+
+def test_bvh_cache_round_trip(mipt, scenes, tmp_path):
+    """Load-if-valid-else-build: a second call returns the same nodes from the file; other
+    inputs or a damaged file fall back to a rebuild."""
+    vtx, idx, _, _ = scenes.random_soup(500, seed=3)
+    lb = mipt.mesh_leaf_bounds(vtx, idx)
+    path = str(tmp_path / "scene.bvh")
+    opt = mipt.bvh_options(**{"bvh.builder": "sah"})
+    a, cached = mipt.build_bvh_cached(lb, path, opt)
+    assert not cached
+    b, cached = mipt.build_bvh_cached(lb, path, opt)
+    assert cached
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    np.testing.assert_array_equal(a.view(np.uint32), mipt.build_bvh(lb, opt).view(np.uint32))
+    # other options: stale, rebuilt and replaced
+    c, cached = mipt.build_bvh_cached(lb, path, mipt.bvh_options(**{"bvh.builder": "median"}))
+    assert not cached
+    # damaged payload: checksum fails, rebuilt
+    raw = bytearray(open(path, "rb").read())
+    raw[200] ^= 0xFF
+    open(path, "wb").write(bytes(raw))
+    d, cached = mipt.build_bvh_cached(lb, path, mipt.bvh_options(**{"bvh.builder": "median"}))
+    assert not cached
+    np.testing.assert_array_equal(c.view(np.uint32), d.view(np.uint32))
