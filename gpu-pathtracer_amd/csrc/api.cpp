@@ -13,6 +13,7 @@
 
 #include "../../include/mipt.h"
 #include "../host/bvh.h"
+#include "build.h"
 #include "internal.h"
 #include "kernels.h"
 
@@ -415,6 +416,143 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     *out = sc.release();
     return PT_OK;
     PT_CATCH
+}
+
+int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int32_t *idx,
+                   uint32_t n_tri, const pt_material *materials, uint32_t n_materials,
+                   const int32_t *material_ids, uint32_t link_encoding, pt_scene **out) {
+    if (!ctx || !vtx || !idx || !out) return fail(PT_ERR_INVALID, "pt_scene_build: null argument");
+    *out = nullptr;
+    if (n_tri == 0 || n_vtx == 0) return fail(PT_ERR_INVALID, "pt_scene_build: empty mesh");
+    if (link_encoding != PT_LINKS_FLOAT_VALUE && link_encoding != PT_LINKS_INT_BITS)
+        return fail(PT_ERR_INVALID, "pt_scene_build: unknown link encoding");
+    if ((materials == nullptr) != (material_ids == nullptr) || (materials && n_materials == 0))
+        return fail(PT_ERR_INVALID,
+                    "pt_scene_build: materials and material_ids must be given together");
+    if (link_encoding == PT_LINKS_FLOAT_VALUE && 2ull * n_tri - 1 > (1u << 24))
+        return fail(PT_ERR_INVALID,
+                    "pt_scene_build: more than 2^24 nodes need PT_LINKS_INT_BITS (indices above "
+                    "2^24 are not exact as float values)");
+    if (n_tri > 89000000u)
+        return fail(PT_ERR_UNSUPPORTED, "pt_scene_build: scene too large for 32-bit record offsets");
+    PT_TRY
+    for (uint64_t i = 0; i < 3ull * n_tri; ++i)
+        if (idx[i] < 0 || (uint32_t)idx[i] >= n_vtx)
+            return fail(PT_ERR_INVALID, "pt_scene_build: index " + std::to_string(idx[i]) +
+                                            " outside the vertex buffer");
+    if (n_tri == 1) {
+        // A one-leaf tree has no inner node to build: take the host path.
+        pt_bbox lb;
+        mesh_leaf_bounds(vtx, idx, 1, &lb);
+        pt_bvh_options opt;
+        pt_bvh_options_default(&opt);
+        opt.link_encoding = link_encoding;
+        pt_bvh *b = nullptr;
+        int rc = pt_bvh_build(&lb, 1, &opt, &b);
+        if (rc != PT_OK) return rc;
+        rc = pt_scene_create(ctx, b->nodes.data(), (uint32_t)b->nodes.size(), link_encoding, vtx,
+                             n_vtx, idx, n_tri, materials, n_materials, material_ids, out);
+        pt_bvh_destroy(b);
+        return rc;
+    }
+    std::vector<pt_material> mats;
+    std::vector<int32_t> mids;
+    if (materials) {
+        mats.assign(materials, materials + n_materials);
+        mids.assign(material_ids, material_ids + n_tri);
+        for (uint32_t t = 0; t < n_tri; ++t)
+            if (mids[t] < 0 || (uint32_t)mids[t] >= n_materials)
+                return fail(PT_ERR_INVALID, "pt_scene_build: material id " +
+                                                std::to_string(mids[t]) + " out of range");
+    } else {
+        pt_material m{};
+        m.kd[0] = m.kd[1] = m.kd[2] = 0.5f;
+        m.roughness = 1.f;
+        mats.push_back(m);
+        mids.assign(n_tri, 0);
+    }
+    std::vector<int32_t> light_tri;
+    std::vector<float> light_cdf;
+    build_light_list(vtx, idx, n_tri, mats.data(), mids.data(), light_tri, light_cdf);
+
+    HIP_CHECK(hipSetDevice(ctx->device));
+    auto sc = std::make_unique<pt_scene>();
+    sc->ctx = ctx;
+    hipError_t e = hipSuccess;
+    auto dev_alloc = [&](void **dst, size_t bytes) -> bool {
+        e = hipMalloc(dst, bytes);
+        if (e != hipSuccess) return false;
+        sc->allocs.push_back(*dst);
+        return true;
+    };
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> bool {
+        if (!dev_alloc(dst, bytes)) return false;
+        e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+        return e == hipSuccess;
+    };
+    const uint32_t n_nodes = 2 * n_tri - 1;
+    void *d_nodes, *d_vtx, *d_idx, *d_wn, *d_wt, *d_mid, *d_mat, *d_lt = nullptr, *d_lc = nullptr;
+    bool ok = upload(&d_vtx, vtx, sizeof(float) * 3 * (size_t)n_vtx) &&
+              upload(&d_idx, idx, sizeof(int32_t) * 3 * (size_t)n_tri) &&
+              upload(&d_mid, mids.data(), sizeof(int32_t) * mids.size()) &&
+              upload(&d_mat, mats.data(), sizeof(pt_material) * mats.size()) &&
+              dev_alloc(&d_nodes, sizeof(pt_bbox) * (size_t)n_nodes) &&
+              dev_alloc(&d_wn, sizeof(WideNode) * (size_t)(n_tri - 1)) &&
+              dev_alloc(&d_wt, sizeof(TriRecord) * (size_t)n_tri);
+    if (ok && !light_tri.empty())
+        ok = upload(&d_lt, light_tri.data(), sizeof(int32_t) * light_tri.size()) &&
+             upload(&d_lc, light_cdf.data(), sizeof(float) * light_cdf.size());
+    if (!ok) {
+        (void)hipStreamSynchronize(ctx->stream);
+        sc->release();
+        return hip_fail(e, "pt_scene_build allocation / upload");
+    }
+    DeviceBuffer scratch;
+    const DeviceBuildResult br = build_scene_on_device(
+        ctx->stream, (const float *)d_vtx, (const int32_t *)d_idx, n_tri, link_encoding, scratch,
+        (float4 *)d_nodes, (float4 *)d_wn, (float4 *)d_wt);
+    (void)hipStreamSynchronize(ctx->stream);
+    scratch.release();
+    if (br.no_memory || br.hip_error != hipSuccess || br.bad_input) {
+        sc->release();
+        if (br.bad_input)
+            return fail(PT_ERR_INVALID, "pt_scene_build: a triangle has a vertex that is not finite");
+        if (br.no_memory) return PT_ERR_DEVICE;      // message set by the failing reserve
+        return hip_fail(br.hip_error, br.what);
+    }
+    DeviceScene &d = sc->dev;
+    d.nodes = (const float4 *)d_nodes;
+    d.vtx = (const float *)d_vtx;
+    d.idx = (const int32_t *)d_idx;
+    d.wnodes = (const float4 *)d_wn;
+    d.wtris = (const float4 *)d_wt;
+    d.mat_ids = (const int32_t *)d_mid;
+    d.materials = (const pt_material *)d_mat;
+    d.light_tri = (const int32_t *)d_lt;
+    d.light_cdf = (const float *)d_lc;
+    d.n_lights = (uint32_t)light_tri.size();
+    d.light_area = light_cdf.empty() ? 0.f : light_cdf.back();
+    d.n_nodes = n_nodes;
+    d.n_tri = n_tri;
+    d.n_wnodes = n_tri - 1;
+    d.n_materials = (uint32_t)mats.size();
+    d.link_enc = link_encoding;
+    d.wide_depth = br.max_depth;
+    *out = sc.release();
+    return PT_OK;
+    PT_CATCH
+}
+
+uint32_t pt_scene_node_count(const pt_scene *scene) { return scene ? scene->dev.n_nodes : 0; }
+uint32_t pt_scene_link_encoding(const pt_scene *scene) { return scene ? scene->dev.link_enc : 0; }
+
+int pt_scene_read_nodes(pt_scene *scene, pt_bbox *nodes) {
+    if (!scene || !nodes) return fail(PT_ERR_INVALID, "pt_scene_read_nodes: null argument");
+    HIP_CHECK(hipSetDevice(scene->ctx->device));
+    HIP_CHECK(hipMemcpyAsync(nodes, scene->dev.nodes, sizeof(pt_bbox) * (size_t)scene->dev.n_nodes,
+                             hipMemcpyDeviceToHost, scene->ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(scene->ctx->stream));
+    return PT_OK;
 }
 
 int pt_scene_destroy(pt_scene *scene) {

@@ -1,0 +1,26 @@
+// Internal interface of the GPU BVH builder (build.hip <-> api.cpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "internal.h"
+
+namespace mipt {
+
+struct DeviceBuildResult {
+    hipError_t hip_error = hipSuccess;   // first failing HIP call, if any
+    const char *what = "";
+    bool no_memory = false;              // the scratch allocation failed
+    bool bad_input = false;              // a triangle's box is not finite
+    uint32_t max_depth = 0;              // levels of the tree, leaves included
+};
+
+// Builds, from device-resident vertices and indices of n >= 2 triangles, the skip-link node
+// array (2n-1 nodes, 2 x float4 each), the two-child nodes (n-1, 4 x float4 each) and the
+// triangle records (n, 3 x float4 each).  Blocks until done.
+DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
+                                        uint32_t n, uint32_t link_encoding, DeviceBuffer &scratch,
+                                        float4 *d_nodes, float4 *d_wnodes, float4 *d_wtris);
+
+} // namespace mipt

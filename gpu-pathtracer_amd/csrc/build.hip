@@ -1,0 +1,409 @@
+// BVH construction on the GPU: the whole of build_mesh_bvh + init_device_data
+// (src/main_granite.cpp:115-194) without the host in the loop.
+//
+//   leaf boxes          src/main_granite.cpp:162-172   (min/max of the three vertices)
+//   inflation           src/bvh/bvh_builder.cpp:53-59  (same binary32 expression as the host)
+//   tree                a linear BVH: triangles ordered by the 63-bit Morton code of their box
+//                       centre, binary radix tree over the codes (Karras 2012).  The topology
+//                       RadeonRays::Bvh::Build would produce is external to the reference, and
+//                       hit results do not depend on it except between exact ties.
+//   boxes               union of the children, one launch per tree level, deepest first
+//   output              the 32-byte skip-link array of src/bvh/bvh_builder.h:26-34 in pre-order
+//                       (PlainBvhTranslator::Process, plain_bvh_translator.cpp:39-96), plus the
+//                       64-byte two-child nodes and 48-byte triangle records of the traversal.
+//
+// No thread reads what another thread of the same launch wrote: every hand-off crosses a
+// kernel boundary, so no in-launch fences or cache-bypassing accesses are needed and the
+// result is deterministic (sort keys are made unique by the triangle index).
+//
+// Pre-order position of a node without a traversal: if the node covers the sorted leaves
+// [first, last] and `lt` of its ancestors hold it in their LEFT subtree, everything left of it
+// (2*first nodes, less one per right turn) plus its ancestors (left + right turns) precede it:
+// position = 2*first + lt.  Among inner nodes alone it is first + lt; among leaves, the leaf's
+// sorted index.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "build.h"
+
+namespace mipt {
+
+namespace {
+
+constexpr int kB = 256;
+constexpr int kMaxDepth = 128;     // 63 code bits + 32 index bits bound the radix tree's depth
+
+__device__ __forceinline__ unsigned int ordered(float f) {      // monotonic float -> uint
+    const unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float unordered(unsigned int u) {
+    const unsigned int b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(b);
+#else
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+#endif
+}
+
+__device__ __forceinline__ float encode_index(int32_t v, uint32_t enc) {
+    return enc == PT_LINKS_INT_BITS ? __int_as_float(v) : (float)v;
+}
+
+// ---- 1. leaf boxes, centre bounds -----------------------------------------------------
+// boxes[t] = inflated box of triangle t (w fields 0).  bounds[0..5]: ordered-uint min x,y,z
+// and max x,y,z of the box centres; bounds[6]: set non-zero if a vertex or box is not finite.
+__global__ __launch_bounds__(kB) void k_leaf_boxes(const float *vtx, const int32_t *idx,
+                                                   uint32_t n, float4 *boxes,
+                                                   unsigned int *bounds) {
+    const float kBoundsScale = 1.f + 1e-4f;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool bad = false;
+    for (uint32_t t = blockIdx.x * kB + threadIdx.x; t < n; t += gridDim.x * kB) {
+        const int32_t i0 = idx[3 * (size_t)t], i1 = idx[3 * (size_t)t + 1], i2 = idx[3 * (size_t)t + 2];
+        const float *a = vtx + 3 * (size_t)i0, *b = vtx + 3 * (size_t)i1, *c = vtx + 3 * (size_t)i2;
+        float mn[3], mx[3];
+        for (int k = 0; k < 3; ++k) {
+            const float pmin = fminf(fminf(a[k], b[k]), c[k]), pmax = fmaxf(fmaxf(a[k], b[k]), c[k]);
+            const float ctr = 0.5f * (pmax + pmin);                    // bvh_builder.cpp:55-58
+            mn[k] = ctr + (pmin - ctr) * kBoundsScale;
+            mx[k] = ctr + (pmax - ctr) * kBoundsScale;
+            const float m = 0.5f * (mn[k] + mx[k]);
+            lo[k] = fminf(lo[k], m);
+            hi[k] = fmaxf(hi[k], m);
+            bad |= !(fabsf(mn[k]) < INFINITY) || !(fabsf(mx[k]) < INFINITY) ||
+                   !(fabsf((a[k] + b[k]) + c[k]) < INFINITY);   // min/max would skip a NaN vertex
+        }
+        boxes[2 * (size_t)t + 0] = make_float4(mn[0], mn[1], mn[2], 0.f);
+        boxes[2 * (size_t)t + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
+    }
+    __shared__ float s_lo[3][kB / 64], s_hi[3][kB / 64];
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    for (int k = 0; k < 3; ++k) {
+        float l = lo[k], h = hi[k];
+        for (int o = 32; o > 0; o >>= 1) {
+            l = fminf(l, __shfl_xor(l, o, 64));
+            h = fmaxf(h, __shfl_xor(h, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_lo[k][threadIdx.x >> 6] = l;
+            s_hi[k][threadIdx.x >> 6] = h;
+        }
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float l = s_lo[k][0], h = s_hi[k][0];
+        for (int w = 1; w < kB / 64; ++w) {
+            l = fminf(l, s_lo[k][w]);
+            h = fmaxf(h, s_hi[k][w]);
+        }
+        if (l <= h) {
+            atomicMin(&bounds[k], ordered(l));
+            atomicMax(&bounds[3 + k], ordered(h));
+        }
+    }
+    if (threadIdx.x == 0 && s_bad) atomicOr(&bounds[6], 1u);
+}
+
+// ---- 2. Morton codes ----------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long spread21(unsigned int v) {
+    unsigned long long x = v & 0x1FFFFFull;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(kB) void k_morton(const float4 *boxes, uint32_t n,
+                                               const unsigned int *bounds,
+                                               unsigned long long *keys, uint32_t *vals) {
+    const uint32_t t = blockIdx.x * kB + threadIdx.x;
+    if (t >= n) return;
+    const float4 mn = boxes[2 * (size_t)t], mx = boxes[2 * (size_t)t + 1];
+    const float c[3] = {0.5f * (mn.x + mx.x), 0.5f * (mn.y + mx.y), 0.5f * (mn.z + mx.z)};
+    unsigned int q[3];
+    for (int k = 0; k < 3; ++k) {
+        const float lo = unordered(bounds[k]), hi = unordered(bounds[3 + k]);
+        const float ext = hi - lo;
+        float x = ext > 0.f ? (c[k] - lo) / ext : 0.f;
+        x = fminf(fmaxf(x * 2097152.f, 0.f), 2097151.f);
+        q[k] = (unsigned int)x;
+    }
+    keys[t] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    vals[t] = t;
+}
+
+// ---- 3. binary radix tree over the sorted codes (Karras 2012) ------------------------------
+// Common-prefix length of sorted positions i and j; equal codes are told apart by position.
+__device__ __forceinline__ int prefix_len(const unsigned long long *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz(i ^ j);
+}
+
+// Inner node i (0 <= i < n-1; 0 is the root): children, covered range, and for both children
+// the parent word (parent << 1 | is_left).  A child is an inner node index, or ~(leaf position).
+__global__ __launch_bounds__(kB) void k_radix_tree(const unsigned long long *keys, int n,
+                                                   int32_t *left, int32_t *right, uint32_t *first,
+                                                   uint32_t *last, uint32_t *inner_parent,
+                                                   uint32_t *leaf_parent) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = prefix_len(keys, n, i, i + 1) > prefix_len(keys, n, i, i - 1) ? 1 : -1;
+    const int dmin = prefix_len(keys, n, i, i - d);
+    int lmax = 2;
+    while (prefix_len(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t > 0; t >>= 1)
+        if (prefix_len(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = prefix_len(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+        if (prefix_len(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    const bool left_leaf = lo == gamma, right_leaf = hi == gamma + 1;
+    left[i] = left_leaf ? ~gamma : gamma;
+    right[i] = right_leaf ? ~(gamma + 1) : gamma + 1;
+    first[i] = (uint32_t)lo;
+    last[i] = (uint32_t)hi;
+    if (left_leaf) leaf_parent[gamma] = ((uint32_t)i << 1) | 1u;
+    else inner_parent[gamma] = ((uint32_t)i << 1) | 1u;
+    if (right_leaf) leaf_parent[gamma + 1] = ((uint32_t)i << 1);
+    else inner_parent[gamma + 1] = ((uint32_t)i << 1);
+}
+
+// ---- 4. depth and left-turn count of every inner node ---------------------------------------
+__global__ __launch_bounds__(kB) void k_depth(const uint32_t *inner_parent, int n_inner,
+                                              uint32_t *depth, uint32_t *lt, uint32_t *ids,
+                                              unsigned int *histogram) {
+    __shared__ unsigned int s_hist[kMaxDepth];
+    if (threadIdx.x < kMaxDepth) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i < n_inner) {
+        uint32_t d = 0, l = 0;
+        for (int cur = i; cur != 0;) {
+            const uint32_t p = inner_parent[cur];
+            l += p & 1u;
+            ++d;
+            cur = (int)(p >> 1);
+        }
+        if (d >= (uint32_t)kMaxDepth) d = kMaxDepth - 1;      // cannot happen (see kMaxDepth)
+        depth[i] = d;
+        lt[i] = l;
+        ids[i] = (uint32_t)i;
+        atomicAdd(&s_hist[d], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kMaxDepth && s_hist[threadIdx.x])
+        atomicAdd(&histogram[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+// ---- 5. boxes of one level --------------------------------------------------------------------
+// ibox: 2 x float4 per inner node.  Children one level down were written by the previous launch.
+__global__ __launch_bounds__(kB) void k_refit_level(const uint32_t *level_ids, uint32_t count,
+                                                    const int32_t *left, const int32_t *right,
+                                                    const uint32_t *vals, const float4 *boxes,
+                                                    float4 *ibox) {
+    const uint32_t k = blockIdx.x * kB + threadIdx.x;
+    if (k >= count) return;
+    const uint32_t i = level_ids[k];
+    const int32_t cl = left[i], cr = right[i];
+    const float4 *bl = cl >= 0 ? ibox + 2 * (size_t)cl : boxes + 2 * (size_t)vals[~cl];
+    const float4 *br = cr >= 0 ? ibox + 2 * (size_t)cr : boxes + 2 * (size_t)vals[~cr];
+    const float4 lmin = bl[0], lmax = bl[1], rmin = br[0], rmax = br[1];
+    ibox[2 * (size_t)i + 0] = make_float4(fminf(lmin.x, rmin.x), fminf(lmin.y, rmin.y),
+                                          fminf(lmin.z, rmin.z), 0.f);
+    ibox[2 * (size_t)i + 1] = make_float4(fmaxf(lmax.x, rmax.x), fmaxf(lmax.y, rmax.y),
+                                          fmaxf(lmax.z, rmax.z), 0.f);
+}
+
+// ---- 6. output ------------------------------------------------------------------------------------
+struct EmitArgs {
+    const int32_t *left, *right;
+    const uint32_t *first, *last, *lt, *leaf_parent, *vals;
+    const float4 *boxes, *ibox;
+    const float *vtx;
+    const int32_t *idx;
+    float4 *nodes;     // 2 x float4 per skip-link node
+    float4 *wnodes;    // 4 x float4 per two-child node
+    float4 *wtris;     // 3 x float4 per triangle record
+    uint32_t n;        // leaves
+    uint32_t enc;
+};
+
+__global__ __launch_bounds__(kB) void k_emit_inner(EmitArgs a) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= a.n - 1) return;
+    const uint32_t total = 2 * a.n - 1;
+    const uint32_t f = a.first[i], cnt = a.last[i] - f + 1, lt = a.lt[i];
+    const uint32_t pos = 2 * f + lt;
+    const uint32_t next = pos + 2 * cnt - 1;
+    const float4 mn = a.ibox[2 * (size_t)i], mx = a.ibox[2 * (size_t)i + 1];
+    a.nodes[2 * (size_t)pos + 0] = make_float4(mn.x, mn.y, mn.z, encode_index(-1, a.enc));
+    a.nodes[2 * (size_t)pos + 1] =
+        make_float4(mx.x, mx.y, mx.z, encode_index(next < total ? (int32_t)next : -1, a.enc));
+    // two-child node, numbered among inner nodes in pre-order
+    const int32_t cl = a.left[i], cr = a.right[i];
+    const float4 *bl = cl >= 0 ? a.ibox + 2 * (size_t)cl : a.boxes + 2 * (size_t)a.vals[~cl];
+    const float4 *br = cr >= 0 ? a.ibox + 2 * (size_t)cr : a.boxes + 2 * (size_t)a.vals[~cr];
+    const float4 lmin = bl[0], lmax = bl[1], rmin = br[0], rmax = br[1];
+    const int32_t ref_l = cl >= 0 ? (int32_t)(a.first[cl] + lt + 1) : ~(3 * (~cl));
+    const int32_t ref_r = cr >= 0 ? (int32_t)(a.first[cr] + lt) : ~(3 * (~cr));
+    float4 *w = a.wnodes + 4 * (size_t)(f + lt);
+    w[0] = make_float4(lmin.x, lmax.x, lmin.y, lmax.y);
+    w[1] = make_float4(rmin.x, rmax.x, rmin.y, rmax.y);
+    w[2] = make_float4(lmin.z, lmax.z, rmin.z, rmax.z);
+    w[3] = make_float4(__int_as_float(ref_l), __int_as_float(ref_r), 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(kB) void k_emit_leaf(EmitArgs a) {
+    const uint32_t l = blockIdx.x * kB + threadIdx.x;
+    if (l >= a.n) return;
+    const uint32_t total = 2 * a.n - 1;
+    const uint32_t p = a.leaf_parent[l];
+    const uint32_t pos = 2 * l + a.lt[p >> 1] + (p & 1u);
+    const uint32_t tri = a.vals[l];
+    const float4 mn = a.boxes[2 * (size_t)tri], mx = a.boxes[2 * (size_t)tri + 1];
+    a.nodes[2 * (size_t)pos + 0] = make_float4(mn.x, mn.y, mn.z, encode_index((int32_t)tri, a.enc));
+    a.nodes[2 * (size_t)pos + 1] =
+        make_float4(mx.x, mx.y, mx.z, encode_index(pos + 1 < total ? (int32_t)(pos + 1) : -1, a.enc));
+    const int32_t i0 = a.idx[3 * (size_t)tri], i1 = a.idx[3 * (size_t)tri + 1],
+                  i2 = a.idx[3 * (size_t)tri + 2];
+    const float *v0 = a.vtx + 3 * (size_t)i0, *v1 = a.vtx + 3 * (size_t)i1, *v2 = a.vtx + 3 * (size_t)i2;
+    float4 *r = a.wtris + 3 * (size_t)l;
+    r[0] = make_float4(v0[0], v0[1], v0[2], v1[0]);
+    r[1] = make_float4(v1[1], v1[2], v2[0], v2[1]);
+    r[2] = make_float4(v2[2], __int_as_float((int32_t)tri), 0.f, 0.f);
+}
+
+inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kB - 1) / kB); }
+
+#define BUILD_CHECK(expr)                                 \
+    do {                                                  \
+        hipError_t _e = (expr);                           \
+        if (_e != hipSuccess) {                           \
+            res.hip_error = _e;                           \
+            res.what = #expr;                             \
+            return res;                                   \
+        }                                                 \
+    } while (0)
+
+} // namespace
+
+DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
+                                        uint32_t n, uint32_t enc, DeviceBuffer &scratch,
+                                        float4 *d_nodes, float4 *d_wnodes, float4 *d_wtris) {
+    DeviceBuildResult res;
+    const uint32_t n_inner = n - 1;
+    // scratch carve-up
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const size_t o_boxes = take(32 * (size_t)n), o_ibox = take(32 * (size_t)n_inner);
+    const size_t o_k0 = take(8 * (size_t)n), o_k1 = take(8 * (size_t)n);
+    const size_t o_v0 = take(4 * (size_t)n), o_v1 = take(4 * (size_t)n);
+    const size_t o_left = take(4 * (size_t)n), o_right = take(4 * (size_t)n);
+    const size_t o_first = take(4 * (size_t)n), o_last = take(4 * (size_t)n);
+    const size_t o_ip = take(4 * (size_t)n), o_lp = take(4 * (size_t)n);
+    const size_t o_depth = take(4 * (size_t)n), o_depth2 = take(4 * (size_t)n);
+    const size_t o_lt = take(4 * (size_t)n);
+    const size_t o_ids = take(4 * (size_t)n), o_ids2 = take(4 * (size_t)n);
+    const size_t o_small = take(4 * (kMaxDepth + 16));
+    size_t sort_bytes = 0, sort2_bytes = 0;
+    BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long *)nullptr,
+                                                   (unsigned long long *)nullptr, (uint32_t *)nullptr,
+                                                   (uint32_t *)nullptr, (int)n, 0, 63, st));
+    BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort2_bytes, (uint32_t *)nullptr,
+                                                   (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                                   (uint32_t *)nullptr, (int)n, 0, 8, st));
+    const size_t o_sort = take(std::max(sort_bytes, sort2_bytes));
+    if (scratch.reserve(off) != PT_OK) {
+        res.no_memory = true;
+        return res;
+    }
+    char *base = (char *)scratch.ptr;
+    float4 *boxes = (float4 *)(base + o_boxes), *ibox = (float4 *)(base + o_ibox);
+    unsigned long long *k0 = (unsigned long long *)(base + o_k0), *k1 = (unsigned long long *)(base + o_k1);
+    uint32_t *v0 = (uint32_t *)(base + o_v0), *v1 = (uint32_t *)(base + o_v1);
+    int32_t *left = (int32_t *)(base + o_left), *right = (int32_t *)(base + o_right);
+    uint32_t *first = (uint32_t *)(base + o_first), *last = (uint32_t *)(base + o_last);
+    uint32_t *iparent = (uint32_t *)(base + o_ip), *lparent = (uint32_t *)(base + o_lp);
+    uint32_t *depth = (uint32_t *)(base + o_depth), *depth2 = (uint32_t *)(base + o_depth2);
+    uint32_t *lt = (uint32_t *)(base + o_lt);
+    uint32_t *ids = (uint32_t *)(base + o_ids), *ids2 = (uint32_t *)(base + o_ids2);
+    unsigned int *small = (unsigned int *)(base + o_small);       // [0..6] bounds, [16..] histogram
+    unsigned int *histogram = small + 16;
+
+    // 1. boxes + centre bounds
+    {
+        unsigned int init[7] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u};
+        BUILD_CHECK(hipMemcpyAsync(small, init, sizeof(init), hipMemcpyHostToDevice, st));
+        BUILD_CHECK(hipMemsetAsync(histogram, 0, 4 * kMaxDepth, st));
+        const unsigned int g = std::min<unsigned int>(grid_for(n), 4096);
+        hipLaunchKernelGGL(k_leaf_boxes, dim3(g), dim3(kB), 0, st, d_vtx, d_idx, n, boxes, small);
+    }
+    // 2. codes, 3. sort
+    hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kB), 0, st, boxes, n, small, k0, v0);
+    BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_sort, sort_bytes, k0, k1, v0, v1, (int)n, 0,
+                                                   63, st));
+    // 4. tree, depths
+    hipLaunchKernelGGL(k_radix_tree, dim3(grid_for(n_inner)), dim3(kB), 0, st, k1, (int)n, left, right,
+                       first, last, iparent, lparent);
+    hipLaunchKernelGGL(k_depth, dim3(grid_for(n_inner)), dim3(kB), 0, st, iparent, (int)n_inner, depth,
+                       lt, ids, histogram);
+    BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_sort, sort2_bytes, depth, depth2, ids, ids2,
+                                                   (int)n_inner, 0, 8, st));
+    unsigned int h_small[16 + kMaxDepth];
+    BUILD_CHECK(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, st));
+    BUILD_CHECK(hipStreamSynchronize(st));
+    if (h_small[6]) {
+        res.bad_input = true;
+        return res;
+    }
+    // 5. boxes level by level, deepest first
+    std::vector<uint32_t> begin(kMaxDepth + 1, 0);
+    for (int d = 0; d < kMaxDepth; ++d) begin[d + 1] = begin[d] + h_small[16 + d];
+    int max_depth = 0;
+    for (int d = kMaxDepth - 1; d >= 0; --d) {
+        const uint32_t cnt = begin[d + 1] - begin[d];
+        if (!cnt) continue;
+        max_depth = std::max(max_depth, d);
+        hipLaunchKernelGGL(k_refit_level, dim3(grid_for(cnt)), dim3(kB), 0, st, ids2 + begin[d], cnt,
+                           left, right, v1, boxes, ibox);
+    }
+    // 6. output
+    EmitArgs a;
+    a.left = left; a.right = right; a.first = first; a.last = last; a.lt = lt;
+    a.leaf_parent = lparent; a.vals = v1; a.boxes = boxes; a.ibox = ibox;
+    a.vtx = d_vtx; a.idx = d_idx;
+    a.nodes = d_nodes; a.wnodes = d_wnodes; a.wtris = d_wtris;
+    a.n = n; a.enc = enc;
+    hipLaunchKernelGGL(k_emit_inner, dim3(grid_for(n_inner)), dim3(kB), 0, st, a);
+    hipLaunchKernelGGL(k_emit_leaf, dim3(grid_for(n)), dim3(kB), 0, st, a);
+    BUILD_CHECK(hipGetLastError());
+    BUILD_CHECK(hipStreamSynchronize(st));
+    res.max_depth = (uint32_t)max_depth + 2;      // inner levels + the leaf level
+    return res;
+}
+
+} // namespace mipt

@@ -123,6 +123,11 @@ _PROTOS = {
     "pt_scene_create": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp,
                                   C.c_uint32, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
     "pt_scene_destroy": (C.c_int, [_vp]),
+    "pt_scene_build": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint32, _vp,
+                                 C.c_uint32, C.POINTER(_vp)]),
+    "pt_scene_node_count": (C.c_uint32, [_vp]),
+    "pt_scene_link_encoding": (C.c_uint32, [_vp]),
+    "pt_scene_read_nodes": (C.c_int, [_vp, _vp]),
     "pt_trace_closest": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32,
                                    C.POINTER(TraceStats)]),
     "pt_trace_closest_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32]),
@@ -333,10 +338,14 @@ class Context:
 
 
 class Scene:
+    """nodes given: ``pt_scene_create`` (any skip-link array).  nodes=None: ``pt_scene_build``,
+    the BVH is built on the GPU from the mesh."""
+
     def __init__(self, ctx: Context, nodes, vtx, idx, materials=None, material_ids=None,
                  link_encoding: int = PT_LINKS_FLOAT_VALUE):
         self.ctx = ctx
-        nodes = _as(nodes, bbox_dtype, "nodes")
+        if nodes is not None:
+            nodes = _as(nodes, bbox_dtype, "nodes")
         vtx = _as(vtx, np.float32, "vtx").reshape(-1, 3)
         idx = _as(idx, np.int32, "idx").reshape(-1, 3)
         mats = mids = None
@@ -347,11 +356,24 @@ class Scene:
                 raise ValueError("material_ids must have one entry per triangle")
         self.n_tri = idx.shape[0]
         self._h = _vp()
+        if nodes is None:
+            _check(lib.pt_scene_build(ctx._h, _ptr(vtx), vtx.shape[0], _ptr(idx), idx.shape[0],
+                                      _ptr(mats) if mats is not None else None,
+                                      mats.shape[0] if mats is not None else 0,
+                                      _ptr(mids) if mids is not None else None, link_encoding,
+                                      C.byref(self._h)))
+            return
         _check(lib.pt_scene_create(ctx._h, _ptr(nodes), nodes.shape[0], link_encoding, _ptr(vtx),
                                    vtx.shape[0], _ptr(idx), idx.shape[0],
                                    _ptr(mats) if mats is not None else None,
                                    mats.shape[0] if mats is not None else 0,
                                    _ptr(mids) if mids is not None else None, C.byref(self._h)))
+
+    def read_nodes(self) -> np.ndarray:
+        """The scene's skip-link node array."""
+        out = np.empty(lib.pt_scene_node_count(self._h), dtype=bbox_dtype)
+        _check(lib.pt_scene_read_nodes(self._h, _ptr(out)))
+        return out
 
     def close(self) -> None:
         if self._h:

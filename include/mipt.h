@@ -189,6 +189,20 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
                     uint32_t link_encoding, const float *vtx, uint32_t n_vtx,
                     const int32_t *idx, uint32_t n_tri, const pt_material *materials,
                     uint32_t n_materials, const int32_t *material_ids, pt_scene **out);
+/* build_mesh_bvh + init_device_data (src/main_granite.cpp:115-194) entirely on the GPU: leaf
+ * boxes (:162-172), their inflation (src/bvh/bvh_builder.cpp:53-59, bit-identical to the host
+ * path), a linear BVH over the Morton-ordered box centres, the skip-link array in the format
+ * of src/bvh/bvh_builder.h:26-34 and the traversal layouts.  Two orders of magnitude faster
+ * than pt_bvh_build + pt_scene_create on large meshes; the tree is of lower quality than the
+ * SAH builder's (more boxes per ray).  The result is deterministic. */
+int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int32_t *idx,
+                   uint32_t n_tri, const pt_material *materials, uint32_t n_materials,
+                   const int32_t *material_ids, uint32_t link_encoding, pt_scene **out);
+/* The scene's skip-link array (what pt_scene_create was given, or what pt_scene_build made):
+ * for validation, caching, or a CPU traversal of the same tree.  Blocking. */
+uint32_t pt_scene_node_count(const pt_scene *scene);
+uint32_t pt_scene_link_encoding(const pt_scene *scene);
+int pt_scene_read_nodes(pt_scene *scene, pt_bbox *nodes);
 int pt_scene_destroy(pt_scene *scene);
 
 /* IntersectSceneClosest, shaders/RadeonRays/bvh.glslh:417-456, for n rays.

@@ -1,0 +1,112 @@
+"""The GPU BVH builder (pt_scene_build) against the same bar as the host builder: the node
+array it produces must be a valid skip-link tree over exactly the reference's inflated leaf
+boxes, and tracing it must give the oracle's hits on that same array, bit for bit.
+
+Topology parity is unpinned for every builder here (RadeonRays::Bvh::Build is external to the
+reference); what is pinned is the format (src/bvh/bvh_builder.h:26-34), the leaf boxes
+(src/main_granite.cpp:162-172 + src/bvh/bvh_builder.cpp:53-59) and the traversal results."""
+import numpy as np
+import pytest
+
+from conftest import random_rays, same_hits
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_tree(mipt, oracle, nodes, vtx, idx, enc):
+    T = idx.shape[0]
+    assert nodes.shape[0] == 2 * T - 1
+    mipt.validate_bvh(nodes, T, enc)                      # structure: pre-order, links, one leaf per triangle
+    raw = nodes.view(np.float32).reshape(-1, 8)
+    field = (lambda c: raw[:, c].view(np.int32)) if enc == mipt.PT_LINKS_INT_BITS else (lambda c: raw[:, c].astype(np.int64))
+    payload, link = field(3), field(7)
+    leaf = payload >= 0
+    assert leaf.sum() == T and sorted(payload[leaf].tolist()) == list(range(T))
+    want = oracle.inflate(oracle.mesh_leaf_bounds(vtx, idx)).view(np.float32).reshape(-1, 8)
+    got = raw[leaf][np.argsort(payload[leaf])]
+    np.testing.assert_array_equal(got[:, [0, 1, 2, 4, 5, 6]].view(np.uint32),
+                                  want[:, [0, 1, 2, 4, 5, 6]].view(np.uint32))
+    # every inner box is exactly the union of its children's (left = i+1, right = link of i+1)
+    inner = np.nonzero(~leaf)[0]
+    l, r = inner + 1, link[inner + 1]
+    np.testing.assert_array_equal(raw[inner, 0:3], np.minimum(raw[l, 0:3], raw[r, 0:3]))
+    np.testing.assert_array_equal(raw[inner, 4:7], np.maximum(raw[l, 4:7], raw[r, 4:7]))
+
+
+@pytest.mark.parametrize("enc", ["float", "int"])
+def test_device_build_soup(mipt, oracle, scenes, gpu_ctx, enc):
+    enc = mipt.PT_LINKS_INT_BITS if enc == "int" else mipt.PT_LINKS_FLOAT_VALUE
+    vtx, idx, _, _ = scenes.random_soup(30000, seed=21)
+    sc = mipt.Scene(gpu_ctx, None, vtx, idx, link_encoding=enc)
+    try:
+        nodes = sc.read_nodes()
+        _check_tree(mipt, oracle, nodes, vtx, idx, enc)
+        rays = random_rays(80000, 4, dtype=mipt.ray_dtype)
+        got = sc.trace_closest(rays)
+        want = oracle.closest(nodes, vtx, idx, rays, nthreads=8, int_bits=enc == mipt.PT_LINKS_INT_BITS)
+        assert len(same_hits(got, want)) == 0
+        assert (got["primid"] >= 0).mean() > 0.2
+        brute = oracle.brute_closest(vtx, idx, rays[:4000], nthreads=8)
+        np.testing.assert_array_equal(got["uvwt"][:4000, 3], brute["uvwt"][:, 3])
+        if enc == mipt.PT_LINKS_FLOAT_VALUE:
+            rays["o"][:, 3] = 8.0
+            np.testing.assert_array_equal(sc.trace_any(rays), oracle.any_hit(nodes, vtx, idx, rays, nthreads=8))
+    finally:
+        sc.close()
+
+
+def test_device_build_is_deterministic_and_handles_duplicates(mipt, oracle, scenes, gpu_ctx):
+    """Coincident triangles share one Morton code: ties are broken by position, every run alike."""
+    vtx, idx, _, _ = scenes.random_soup(2000, seed=2)
+    idx = np.concatenate([idx, idx[:500], idx[:500]])          # exact duplicates
+    a = mipt.Scene(gpu_ctx, None, vtx, idx)
+    b = mipt.Scene(gpu_ctx, None, vtx, idx)
+    try:
+        na, nb = a.read_nodes(), b.read_nodes()
+        np.testing.assert_array_equal(na.view(np.uint32), nb.view(np.uint32))
+        _check_tree(mipt, oracle, na, vtx, idx, mipt.PT_LINKS_FLOAT_VALUE)
+        rays = random_rays(30000, 8, dtype=mipt.ray_dtype)
+        assert len(same_hits(a.trace_closest(rays), oracle.closest(na, vtx, idx, rays, nthreads=8))) == 0
+    finally:
+        a.close()
+        b.close()
+
+
+def test_device_build_small_and_degenerate(mipt, oracle, scenes, gpu_ctx):
+    # two triangles (one inner node), one triangle (host path), all centres equal, flat scene
+    vtx, idx, _, _ = scenes.fallback_quad()
+    for tri in (idx, idx[:1]):
+        sc = mipt.Scene(gpu_ctx, None, vtx, tri)
+        nodes = sc.read_nodes()
+        _check_tree(mipt, oracle, nodes, vtx, tri, mipt.PT_LINKS_FLOAT_VALUE)
+        rays = random_rays(5000, 1, extent=2.0, dtype=mipt.ray_dtype)
+        assert len(same_hits(sc.trace_closest(rays), oracle.closest(nodes, vtx, tri, rays))) == 0
+        sc.close()
+    same = np.tile(np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]), (50, 1))
+    idx50 = np.arange(150, dtype=np.int32).reshape(50, 3)
+    sc = mipt.Scene(gpu_ctx, None, same, idx50)
+    _check_tree(mipt, oracle, sc.read_nodes(), same, idx50, mipt.PT_LINKS_FLOAT_VALUE)
+    sc.close()
+    bad = vtx.copy()
+    bad[0, 0] = np.nan
+    with pytest.raises(mipt.MiptError, match="not finite"):
+        mipt.Scene(gpu_ctx, None, bad, idx)
+    with pytest.raises(mipt.MiptError, match="outside the vertex buffer"):
+        mipt.Scene(gpu_ctx, None, vtx, np.int32([[0, 1, 99]]))
+
+
+def test_device_build_renders_like_the_oracle(mipt, oracle, scenes, gpu_ctx):
+    """Path tracing over a GPU-built tree: the film equals the CPU restatement run on the
+    tree read back from the device."""
+    vtx, idx, mats, mids = scenes.cornell_box()
+    sc = mipt.Scene(gpu_ctx, None, vtx, idx, mats, mids)
+    film = mipt.Film(gpu_ctx, 64, 64)
+    try:
+        cam = mipt.look_at_camera((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), fovy_deg=39.3)
+        p = mipt.render_params(64, 64, sample_count=4, max_depth=4, flags=mipt.PT_RENDER_NEE)
+        mipt.render(gpu_ctx, sc, cam, p, film)
+        want, _ = oracle.render(sc.read_nodes(), vtx, idx, mats, mids, cam, p, nthreads=8)
+        np.testing.assert_array_equal(film.read().view(np.uint32), want.view(np.uint32))
+    finally:
+        film.close()
+        sc.close()
