@@ -365,6 +365,17 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     std::vector<int32_t> light_tri;
     std::vector<float> light_cdf;
     build_light_list(vtx, idx, n_tri, mats.data(), mids.data(), light_tri, light_cdf);
+    std::vector<TriRecord> stris(n_tri);
+    for (uint32_t t = 0; t < n_tri; ++t) {
+        const float *a = vtx + 3 * (size_t)idx[3 * (size_t)t], *b = vtx + 3 * (size_t)idx[3 * (size_t)t + 1],
+                    *c = vtx + 3 * (size_t)idx[3 * (size_t)t + 2];
+        TriRecord &r = stris[t];
+        r.v0[0] = a[0]; r.v0[1] = a[1]; r.v0[2] = a[2];
+        r.v1x = b[0]; r.v1yz[0] = b[1]; r.v1yz[1] = b[2];
+        r.v2xy[0] = c[0]; r.v2xy[1] = c[1]; r.v2z = c[2];
+        r.primid = mids[t];                     // this copy carries the material id
+        r.pad[0] = r.pad[1] = 0;
+    }
 
     auto sc = std::make_unique<pt_scene>();
     sc->ctx = ctx;
@@ -374,7 +385,7 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
         sc->allocs.push_back(*dst);
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
-    void *d_nodes, *d_vtx, *d_idx, *d_wn, *d_wt, *d_mid, *d_mat, *d_lt = nullptr, *d_lc = nullptr;
+    void *d_nodes, *d_vtx, *d_idx, *d_wn, *d_wt, *d_st, *d_mid, *d_mat, *d_lt = nullptr, *d_lc = nullptr;
     if (wide.nodes.size() > (1u << 26) || wide.tris.size() > 89000000u)
         return fail(PT_ERR_UNSUPPORTED, "pt_scene_create: scene too large for 32-bit record offsets");
     hipError_t e;
@@ -388,6 +399,7 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     UP(d_idx, idx, sizeof(int32_t) * 3 * (size_t)n_tri);
     UP(d_wn, wide.nodes.data(), sizeof(WideNode) * wide.nodes.size());
     UP(d_wt, wide.tris.data(), sizeof(TriRecord) * wide.tris.size());
+    UP(d_st, stris.data(), sizeof(TriRecord) * stris.size());
     UP(d_mid, mids.data(), sizeof(int32_t) * mids.size());
     UP(d_mat, mats.data(), sizeof(pt_material) * mats.size());
     if (!light_tri.empty()) {
@@ -401,6 +413,7 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     d.idx = (const int32_t *)d_idx;
     d.wnodes = (const float4 *)d_wn;
     d.wtris = (const float4 *)d_wt;
+    d.stris = (const float4 *)d_st;
     d.mat_ids = (const int32_t *)d_mid;
     d.materials = (const pt_material *)d_mat;
     d.light_tri = (const int32_t *)d_lt;
@@ -491,14 +504,15 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
         return e == hipSuccess;
     };
     const uint32_t n_nodes = 2 * n_tri - 1;
-    void *d_nodes, *d_vtx, *d_idx, *d_wn, *d_wt, *d_mid, *d_mat, *d_lt = nullptr, *d_lc = nullptr;
+    void *d_nodes, *d_vtx, *d_idx, *d_wn, *d_wt, *d_st, *d_mid, *d_mat, *d_lt = nullptr, *d_lc = nullptr;
     bool ok = upload(&d_vtx, vtx, sizeof(float) * 3 * (size_t)n_vtx) &&
               upload(&d_idx, idx, sizeof(int32_t) * 3 * (size_t)n_tri) &&
               upload(&d_mid, mids.data(), sizeof(int32_t) * mids.size()) &&
               upload(&d_mat, mats.data(), sizeof(pt_material) * mats.size()) &&
               dev_alloc(&d_nodes, sizeof(pt_bbox) * (size_t)n_nodes) &&
               dev_alloc(&d_wn, sizeof(WideNode) * (size_t)(n_tri - 1)) &&
-              dev_alloc(&d_wt, sizeof(TriRecord) * (size_t)n_tri);
+              dev_alloc(&d_wt, sizeof(TriRecord) * (size_t)n_tri) &&
+              dev_alloc(&d_st, sizeof(TriRecord) * (size_t)n_tri);
     if (ok && !light_tri.empty())
         ok = upload(&d_lt, light_tri.data(), sizeof(int32_t) * light_tri.size()) &&
              upload(&d_lc, light_cdf.data(), sizeof(float) * light_cdf.size());
@@ -510,7 +524,7 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
     DeviceBuffer scratch;
     const DeviceBuildResult br = build_scene_on_device(
         ctx->stream, (const float *)d_vtx, (const int32_t *)d_idx, n_tri, link_encoding, scratch,
-        (float4 *)d_nodes, (float4 *)d_wn, (float4 *)d_wt);
+        (const int32_t *)d_mid, (float4 *)d_nodes, (float4 *)d_wn, (float4 *)d_wt, (float4 *)d_st);
     (void)hipStreamSynchronize(ctx->stream);
     scratch.release();
     if (br.no_memory || br.hip_error != hipSuccess || br.bad_input) {
@@ -526,6 +540,7 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
     d.idx = (const int32_t *)d_idx;
     d.wnodes = (const float4 *)d_wn;
     d.wtris = (const float4 *)d_wt;
+    d.stris = (const float4 *)d_st;
     d.mat_ids = (const int32_t *)d_mid;
     d.materials = (const pt_material *)d_mat;
     d.light_tri = (const int32_t *)d_lt;

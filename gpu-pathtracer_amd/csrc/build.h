@@ -18,9 +18,11 @@ struct DeviceBuildResult {
 
 // Builds, from device-resident vertices and indices of n >= 2 triangles, the skip-link node
 // array (2n-1 nodes, 2 x float4 each), the two-child nodes (n-1, 4 x float4 each) and the
-// triangle records (n, 3 x float4 each).  Blocks until done.
+// triangle records (n, 3 x float4 each) in leaf order, and the shading records (the same
+// vertices with the material id, in the caller's triangle order).  Blocks until done.
 DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
                                         uint32_t n, uint32_t link_encoding, DeviceBuffer &scratch,
-                                        float4 *d_nodes, float4 *d_wnodes, float4 *d_wtris);
+                                        const int32_t *d_mat_ids, float4 *d_nodes,
+                                        float4 *d_wnodes, float4 *d_wtris, float4 *d_stris);
 
 } // namespace mipt

@@ -244,6 +244,8 @@ struct EmitArgs {
     float4 *nodes;     // 2 x float4 per skip-link node
     float4 *wnodes;    // 4 x float4 per two-child node
     float4 *wtris;     // 3 x float4 per triangle record
+    float4 *stris;     // 3 x float4 per shading record, by triangle id
+    const int32_t *mat_ids;
     uint32_t n;        // leaves
     uint32_t enc;
 };
@@ -291,6 +293,10 @@ __global__ __launch_bounds__(kB) void k_emit_leaf(EmitArgs a) {
     r[0] = make_float4(v0[0], v0[1], v0[2], v1[0]);
     r[1] = make_float4(v1[1], v1[2], v2[0], v2[1]);
     r[2] = make_float4(v2[2], __int_as_float((int32_t)tri), 0.f, 0.f);
+    float4 *q = a.stris + 3 * (size_t)tri;
+    q[0] = r[0];
+    q[1] = r[1];
+    q[2] = make_float4(v2[2], __int_as_float(a.mat_ids[tri]), 0.f, 0.f);
 }
 
 inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kB - 1) / kB); }
@@ -309,7 +315,8 @@ inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kB - 1) / 
 
 DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
                                         uint32_t n, uint32_t enc, DeviceBuffer &scratch,
-                                        float4 *d_nodes, float4 *d_wnodes, float4 *d_wtris) {
+                                        const int32_t *d_mat_ids, float4 *d_nodes,
+                                        float4 *d_wnodes, float4 *d_wtris, float4 *d_stris) {
     DeviceBuildResult res;
     const uint32_t n_inner = n - 1;
     // scratch carve-up
@@ -397,6 +404,7 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
     a.leaf_parent = lparent; a.vals = v1; a.boxes = boxes; a.ibox = ibox;
     a.vtx = d_vtx; a.idx = d_idx;
     a.nodes = d_nodes; a.wnodes = d_wnodes; a.wtris = d_wtris;
+    a.stris = d_stris; a.mat_ids = d_mat_ids;
     a.n = n; a.enc = enc;
     hipLaunchKernelGGL(k_emit_inner, dim3(grid_for(n_inner)), dim3(kB), 0, st, a);
     hipLaunchKernelGGL(k_emit_leaf, dim3(grid_for(n)), dim3(kB), 0, st, a);

@@ -17,6 +17,9 @@ struct DeviceScene {
     // Re-laid-out copies for the ordered traversal.
     const float4 *wnodes;  // 4 x float4 per two-child node (64 B)
     const float4 *wtris;   // 3 x float4 per triangle record (48 B), leaf order
+    // For shading: the same 48-byte record per triangle in the caller's triangle order, with
+    // the material id where the traversal record keeps the triangle id.
+    const float4 *stris;
     const int32_t *mat_ids;
     const pt_material *materials;
     // Emissive triangles (ascending) and the running sum of their areas.

@@ -149,16 +149,17 @@ struct ShadeResult {
     V3 direct;       //   radiance to add if it reaches the light
 };
 
-// Triangle vertices by index.
-struct TriVerts { V3 v0, v1, v2; };
-__device__ __forceinline__ TriVerts fetch_tri(const float *vtx, const int32_t *idx, int32_t tri) {
-    const int64_t t3 = 3 * (int64_t)tri;
-    const float *p0 = vtx + 3 * (int64_t)idx[t3 + 0], *p1 = vtx + 3 * (int64_t)idx[t3 + 1],
-                *p2 = vtx + 3 * (int64_t)idx[t3 + 2];
+// Vertices and material id of a triangle from its 48-byte shading record (one contiguous
+// fetch instead of an index triple and three vertex gathers).
+struct TriVerts { V3 v0, v1, v2; int32_t material; };
+__device__ __forceinline__ TriVerts fetch_tri(const float4 *stris, int32_t tri) {
+    const float4 *p = stris + 3 * (int64_t)tri;
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2];
     TriVerts r;
-    r.v0 = v3(p0[0], p0[1], p0[2]);
-    r.v1 = v3(p1[0], p1[1], p1[2]);
-    r.v2 = v3(p2[0], p2[1], p2[2]);
+    r.v0 = v3(q0.x, q0.y, q0.z);
+    r.v1 = v3(q0.w, q1.x, q1.y);
+    r.v2 = v3(q1.z, q1.w, q2.x);
+    r.material = __float_as_int(q2.y);
     return r;
 }
 
@@ -177,10 +178,8 @@ __device__ __forceinline__ ShadeResult shade_vertex(const pt_material &m, V3 v0,
                                                     V3 thr, uint32_t key, uint32_t bounce,
                                                     uint32_t max_depth, uint32_t rr_start,
                                                     float ray_offset, bool nee,
-                                                    const LightList &lights, const float *vtx,
-                                                    const int32_t *idx,
-                                                    const pt_material *materials,
-                                                    const int32_t *mat_ids, float q_in,
+                                                    const LightList &lights, const float4 *stris,
+                                                    const pt_material *materials, float q_in,
                                                     float t_hit) {
     ShadeResult r;
     r.alive = false;
@@ -240,7 +239,7 @@ __device__ __forceinline__ ShadeResult shade_vertex(const pt_material &m, V3 v0,
         const float ub = rnd(key, dim0 + DIM_L2);
         const uint32_t li = cdf_find(lights.cdf, lights.count, u_sel * lights.area);
         const int32_t lt = lights.tri[li];
-        const TriVerts L = fetch_tri(vtx, idx, lt);
+        const TriVerts L = fetch_tri(stris, lt);
         const float su = sqrtf(ua);
         const float c0 = 1.0f - su, c1 = ub * su;
         const float c2 = (1.0f - c0) - c1;
@@ -256,7 +255,7 @@ __device__ __forceinline__ ShadeResult shade_vertex(const pt_material &m, V3 v0,
             const float cos_l = fabsf(vdot(lc, wi)) / sqrtf(ll2);
             const float pl = dist2 / (cos_l * lights.area);
             if (n_wi > 0.0f && cos_l > 0.0f && pl > 0.0f) {
-                const pt_material lm = materials[mat_ids[lt]];
+                const pt_material lm = materials[L.material];
                 // Lambert lobe
                 const float qd = (1.0f - p_spec) * (n_wi * PT_INV_PI);
                 V3 f = vscale(kd, (n_wi * PT_INV_PI) * mis_weight(pl, qd));

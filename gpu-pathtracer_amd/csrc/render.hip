@@ -135,15 +135,16 @@ __global__ __launch_bounds__(kWideBlock) void k_pt_shade(DeviceScene s, RenderLa
         const float4 hu = reinterpret_cast<const float4 *>(ws.hits + i)[1];
         const float4 thr4 = ws.throughput[pid];
         const V3 thr = v3(thr4.x, thr4.y, thr4.z);
-        float4 L = ws.radiance[pid];
+        // Radiance this vertex adds to its path, in two ordered terms; the path's slot is only
+        // touched when one is non-zero (adding zeros would not change it).
+        V3 add0 = v3(0, 0, 0), add1 = v3(0, 0, 0);
         if (hi.y < 0) {                                     // left the scene
-            L.x += thr.x * rl.p.background[0];
-            L.y += thr.y * rl.p.background[1];
-            L.z += thr.z * rl.p.background[2];
+            add0 = v3(thr.x * rl.p.background[0], thr.y * rl.p.background[1],
+                      thr.z * rl.p.background[2]);
         } else {
             const float4 rd4 = reinterpret_cast<const float4 *>(ws.rays[buf_in] + i)[1];
-            const TriVerts tv = fetch_tri(s.vtx, s.idx, hi.y);
-            const pt_material m = s.materials[s.mat_ids[hi.y]];
+            const TriVerts tv = fetch_tri(s.stris, hi.y);
+            const pt_material m = s.materials[tv.material];
             LightList lights;
             lights.tri = s.light_tri;
             lights.cdf = s.light_cdf;
@@ -151,11 +152,9 @@ __global__ __launch_bounds__(kWideBlock) void k_pt_shade(DeviceScene s, RenderLa
             lights.area = s.light_area;
             const ShadeResult r = shade_vertex(
                 m, tv.v0, tv.v1, tv.v2, hu.x, hu.y, hu.z, v3(rd4.x, rd4.y, rd4.z), thr, ws.key[pid],
-                bounce, rl.p.max_depth, rl.p.rr_start_depth, rl.p.ray_offset, nee, lights, s.vtx,
-                s.idx, s.materials, s.mat_ids, thr4.w, hu.w);
-            L.x += r.emitted.x;
-            L.y += r.emitted.y;
-            L.z += r.emitted.z;
+                bounce, rl.p.max_depth, rl.p.rr_start_depth, rl.p.ray_offset, nee, lights, s.stris,
+                s.materials, thr4.w, hu.w);
+            add0 = r.emitted;
             alive = r.alive;
             if (alive) {
                 ws.throughput[pid] = make_float4(r.throughput.x, r.throughput.y, r.throughput.z, r.q);
@@ -167,13 +166,18 @@ __global__ __launch_bounds__(kWideBlock) void k_pt_shade(DeviceScene s, RenderLa
                     shadow = true;
                     so = r.so; sd = r.sd; carry = r.direct; smax = r.smax;
                 } else {                                    // no room for an occluder
-                    L.x += r.direct.x;
-                    L.y += r.direct.y;
-                    L.z += r.direct.z;
+                    add1 = r.direct;
                 }
             }
         }
-        ws.radiance[pid] = L;
+        if (add0.x != 0.f || add0.y != 0.f || add0.z != 0.f || add1.x != 0.f || add1.y != 0.f ||
+            add1.z != 0.f) {
+            float4 L = ws.radiance[pid];
+            L.x = (L.x + add0.x) + add1.x;
+            L.y = (L.y + add0.y) + add1.y;
+            L.z = (L.z + add0.z) + add1.z;
+            ws.radiance[pid] = L;
+        }
     }
     const uint32_t slot = block_queue_append(alive, count_out, s_q);
     if (alive) {
