@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--nee", action="store_true",
                     help="next-event estimation: one shadow ray per path vertex (counted in value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-scale", type=int, default=2,
+    ap.add_argument("--cpu-baseline-scale", type=int, default=1,
                     help="the CPU baseline renders the frame at 1/scale resolution in x and y")
     return ap.parse_args()
 
@@ -199,8 +199,11 @@ def main():
             out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"] / 1e9
             out["roofline"]["traffic_unit"] = "GB per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)"
             out["roofline"]["algorithmic_gb_per_launch"] = bytes_per_ray * rays / max(launches, 1) / 1e9
+            if "counters" in tr:
+                out["roofline"]["counters"] = tr["counters"]
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, nodes, vtx, idx, mats, mids, sky)
+            out["traversal_counts_same_rays"] = traversal_counts(scene, nodes, vtx, idx)
         print(json.dumps(out), flush=True)
     film.close()
     scene.close()
@@ -223,15 +226,42 @@ def cpu_baseline(args, nodes, vtx, idx, mats, mids, sky):
     s = max(1, args.cpu_baseline_scale)
     w, h = args.width // s, args.height // s
     cam = scenes.atrium_camera(w / h)
-    p = mipt.render_params(w, h, sample_begin=0, sample_count=args.spp_per_step, max_depth=args.depth,
-                           seed=42, rr_start_depth=3, background=sky,
+    steps = 3                                   # about 10 s of work on 16 cores
+    p = mipt.render_params(w, h, sample_begin=0, sample_count=steps * args.spp_per_step,
+                           max_depth=args.depth, seed=42, rr_start_depth=3, background=sky,
                            flags=mipt.PT_RENDER_NEE if args.nee else 0)
     t0 = time.perf_counter()
     _, rays = oracle.render(nodes, vtx, idx, mats, mids, cam, p, nthreads=cores)
     dt = time.perf_counter() - t0
+    # one core, on a quarter of that sample again
+    w1, h1 = max(w // 2, 8), max(h // 2, 8)
+    p1 = mipt.render_params(w1, h1, sample_begin=0, sample_count=args.spp_per_step, max_depth=args.depth,
+                            seed=42, rr_start_depth=3, background=sky,
+                            flags=mipt.PT_RENDER_NEE if args.nee else 0)
+    t1 = time.perf_counter()
+    _, rays1 = oracle.render(nodes, vtx, idx, mats, mids, scenes.atrium_camera(w1 / h1), p1, nthreads=1)
+    dt1 = time.perf_counter() - t1
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "one step of the same frame at %dx%d (1/%d of the pixels), %d spp, depth %d: "
-                      "%d rays in %.1f s" % (w, h, s * s, args.spp_per_step, args.depth, rays, dt)}
+            "single_core_value": rays1 / dt1 / 1e6,
+            "single_core_sample": "one step at %dx%d: %d rays in %.1f s" % (w1, h1, rays1, dt1),
+            "sample": "%d steps of the same frame at %dx%d (1/%d of the pixels), %d spp each, depth %d: "
+                      "%d rays in %.1f s" % (steps, w, h, s * s, args.spp_per_step, args.depth, rays, dt)}
+
+
+def traversal_counts(scene, nodes, vtx, idx, n=1 << 18):
+    """Slab and triangle tests per ray of the product's ordered traversal and of the
+    reference's skip-link order (CPU restatement), on one set of secondary rays."""
+    import torch
+    from mipt import scenes
+    from oracle import oracle
+    rays = scenes.surface_rays(vtx, idx, n, seed=7)
+    d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
+    d_h = torch.empty_like(d_r)
+    st = scene.trace_closest_device_counted(d_r.data_ptr(), n, d_h.data_ptr())
+    cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", 64))))
+    _, cnt = oracle.closest(nodes, vtx, idx, rays, nthreads=cores, counters=True)
+    return {"rays": n, "ordered": {"box_tests_per_ray": st.box_tests / n, "tri_tests_per_ray": st.tri_tests / n},
+            "skip_link_oracle": {"box_tests_per_ray": cnt.box_tests / n, "tri_tests_per_ray": cnt.tri_tests / n}}
 
 
 if __name__ == "__main__":
