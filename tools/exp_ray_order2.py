@@ -1,0 +1,76 @@
+"""Experiment: what re-ordering a path tracer's bounce queues by origin cell would buy.
+Emulates the queues of the wavefront loop with numpy (camera rays in row-major order, diffuse
+bounces in compaction order) and times the closest-hit kernel on each queue as is and sorted
+by a Morton code of the origin at several resolutions."""
+import json
+import sys, os
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "gpu-pathtracer_amd"))
+import time
+import numpy as np
+import torch
+import mipt
+from mipt import scenes
+
+
+def morton3(q, bits):
+    key = np.zeros(q.shape[0], dtype=np.uint64)
+    for b in range(bits):
+        for k in range(3):
+            key |= ((q[:, k] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + (2 - k))
+    return key
+
+
+def rate(sc, ctx, rays):
+    n = rays.shape[0]
+    d_r = torch.from_numpy(np.ascontiguousarray(rays).view(np.float32).reshape(-1, 8)).cuda()
+    d_h = torch.empty_like(d_r)
+    sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr()); ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr())
+    ctx.synchronize()
+    return n / ((time.perf_counter() - t0) / 5) / 1e6, d_h.cpu().numpy().view(mipt.hit_dtype).reshape(-1)
+
+
+def main():
+    ctx = mipt.Context(0)
+    st = torch.cuda.Stream(); torch.cuda.set_stream(st); ctx.set_stream(st.cuda_stream)
+    vtx, idx, mats, mids = scenes.atrium(262144, seed=42)
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+    sc = mipt.Scene(ctx, nodes, vtx, idx)
+    W, H = 1920, 1080
+    rays = np.tile(ctx.raygen(scenes.atrium_camera(W / H), W, H), 2)     # 2 spp
+    rng = np.random.default_rng(3)
+    lo, hi = vtx.min(0), vtx.max(0)
+    for bounce in range(5):
+        r0, hits = rate(sc, ctx, rays)
+        o = rays["o"][:, :3]
+        out = {"bounce": bounce, "rays": int(rays.shape[0]), "as_is": r0}
+        if bounce > 0:
+            for bits in (4, 5, 7, 10):
+                q = np.clip(((o - lo) / (hi - lo) * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1).astype(np.uint64)
+                perm = np.argsort(morton3(q, bits), kind="stable")
+                out["sorted_%d_bits" % (3 * bits)] = rate(sc, ctx, rays[perm])[0]
+        print(json.dumps(out), flush=True)
+        # next queue: survivors in order, cosine-weighted bounce about the geometric normal
+        hit = hits["primid"] >= 0
+        if bounce >= 2:
+            hit &= rng.random(hit.shape[0]) < 0.8                                   # roulette
+        t = hits["uvwt"][hit, 3:4]
+        d = rays["d"][hit, :3]
+        p = rays["o"][hit, :3] + d * t
+        tri = idx[hits["primid"][hit]]
+        n = np.cross(vtx[tri[:, 1]] - vtx[tri[:, 0]], vtx[tri[:, 2]] - vtx[tri[:, 0]])
+        n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-20)
+        n = np.where((n * d).sum(1, keepdims=True) > 0, -n, n)
+        v = rng.normal(size=n.shape); v /= np.linalg.norm(v, axis=1, keepdims=True)
+        nd = n + v; nd /= np.maximum(np.linalg.norm(nd, axis=1, keepdims=True), 1e-20)
+        rays = np.zeros(p.shape[0], dtype=mipt.ray_dtype)
+        rays["o"][:, :3] = p + n * 1e-3
+        rays["o"][:, 3] = 1e30
+        rays["d"][:, :3] = nd
+    sc.close()
+
+
+main()
