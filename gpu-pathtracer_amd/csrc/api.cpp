@@ -287,6 +287,9 @@ int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
     } else if (k == "extend.leaf_lanes") {
         if (v < 1 || v > 64) return fail(PT_ERR_INVALID, "extend.leaf_lanes must be in [1,64]");
         ctx->extend_leaf_lanes = (int)v;
+    } else if (k == "trace.sort_rays") {
+        if (v < -1 || v > 1) return fail(PT_ERR_INVALID, "trace.sort_rays must be -1, 0 or 1");
+        ctx->trace_sort_rays = (int)v;
     } else if (k == "any.exact_order") {
         ctx->any_exact_order = v != 0;
     } else if (k == "extend.refill") {
@@ -596,8 +599,14 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
         launch_trace_skiplink(st, scene->dev, rays_dev, hits_dev, n, mt,
                               count ? ctx->counters : nullptr);
     } else {
-        launch_trace_ordered(st, scene->dev, rays_dev, hits_dev, n, fixup, ctx->counters, count,
-                             ctx->extend_config());
+        ExtendConfig cfg = ctx->extend_config();
+        // Taking the rays in origin-cell order pays once the traversal layouts no longer fit
+        // the 256 MB Infinity Cache and the call is large enough to amortise the sort.
+        const uint64_t scene_bytes = 64ull * scene->dev.n_wnodes + 48ull * scene->dev.n_tri;
+        cfg.sort_rays = ctx->trace_sort_rays >= 0 ? ctx->trace_sort_rays
+                                                  : (scene_bytes > (256ull << 20) && n >= (1u << 18));
+        launch_trace_ordered(st, scene->dev, rays_dev, hits_dev, n, fixup, ctx->counters, count, cfg,
+                             &ctx->sort_scratch);
     }
     HIP_CHECK(hipGetLastError());
     if (stats) {

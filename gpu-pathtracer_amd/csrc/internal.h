@@ -36,10 +36,12 @@ struct pt_context {
     int extend_leaf_lanes = 16;     // option "extend.leaf_lanes"
     int extend_blocks_per_cu = 6;   // option "extend.blocks_per_cu"
     int any_exact_order = 0;        // option "any.exact_order"
+    int trace_sort_rays = -1;       // option "trace.sort_rays": 0 off, 1 on, -1 by scene size
     mipt::DeviceTraceCounters *counters = nullptr;
     mipt::DeviceBuffer io_rays;     // staging for the host-pointer entry points
     mipt::DeviceBuffer io_hits;
     mipt::DeviceBuffer render_ws;   // wavefront state of pt_render
+    mipt::DeviceBuffer sort_scratch;    // keys and order of a sorted trace call
     mipt::DeviceBuffer render_counts;   // queue sizes per pass and bounce
     std::vector<hipEvent_t> events;     // pool for per-kernel timing
 
@@ -50,6 +52,7 @@ struct pt_context {
         c.blocks_per_cu = extend_blocks_per_cu;
         c.refill = extend_refill;
         c.leaf_lanes = extend_leaf_lanes;
+        c.sort_rays = 0;
         return c;
     }
 
@@ -60,6 +63,7 @@ struct pt_context {
         io_rays.release();
         io_hits.release();
         render_ws.release();
+        sort_scratch.release();
         if (counters) (void)hipFree(counters);
         counters = nullptr;
         if (own_stream) (void)hipStreamDestroy(own_stream);

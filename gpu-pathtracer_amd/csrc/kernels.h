@@ -8,6 +8,8 @@
 
 namespace mipt {
 
+struct DeviceBuffer;
+
 // Device-resident scene, passed to kernels by value.
 struct DeviceScene {
     // The three buffers the reference shader binds (shaders/RadeonRays/bvh.glslh:103-117).
@@ -47,6 +49,7 @@ struct ExtendConfig {
     int blocks_per_cu;      // persistent form: upper bound on workgroups per compute unit
     int refill;             // persistent form: top up a wave when this many lanes are idle
     int leaf_lanes;         // persistent form: triangle step once this many lanes wait at one
+    int sort_rays;          // trace calls, persistent form: take the rays in origin-cell order
 };
 
 // Closest hit in the reference's fixed skip-link order.
@@ -58,7 +61,7 @@ void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *r
 // in the fixed order inside the same kernel.
 void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                           uint64_t n, bool fixup, DeviceTraceCounters *counters,
-                          bool count_work, const ExtendConfig &cfg);
+                          bool count_work, const ExtendConfig &cfg, DeviceBuffer *sort_scratch);
 
 // Workgroups of `block` threads a persistent kernel may launch and still have them all
 // resident: compute units x min(cap, what the occupancy query admits).

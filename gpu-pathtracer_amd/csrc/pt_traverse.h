@@ -502,13 +502,15 @@ struct HitSink {
 // stream whenever `refill` or more of them have finished, instead of idling them until its
 // slowest ray ends.  Every wave reaches the end of its finite stream, so the grid always
 // drains.  ANY = false: closest hits, sink(ray, shapeid, primid, b0, b1, b2, t).
-// ANY = true: occlusion queries, sink(ray, occluded).
+// ANY = true: occlusion queries, sink(ray, occluded).  perm, if not null, is the order in
+// which to take the rays (queue position -> ray index); sinks always get the ray index.
 template <bool COUNT, bool ANY, class Sink>
 __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const pt_ray *rays,
                                                     uint32_t n, bool fixup, int refill,
                                                     int leaf_lanes, int32_t *stack,
                                                     unsigned int *tie_count,
-                                                    DeviceTraceCounters *work, Sink sink) {
+                                                    DeviceTraceCounters *work, Sink sink,
+                                                    const uint32_t *perm = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (kTraceBlock / 64) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (kTraceBlock / 64);
@@ -560,11 +562,12 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
             if (idle && p < stream_len) {
                 const uint32_t idx = (((p >> 6) * n_waves + wave) << 6) + (p & 63u);
                 if (idx < n) {
-                    const float4 ro = reinterpret_cast<const float4 *>(rays + idx)[0];
-                    const float4 rd = reinterpret_cast<const float4 *>(rays + idx)[1];
+                    const uint32_t ri = perm ? perm[idx] : idx;
+                    const float4 ro = reinterpret_cast<const float4 *>(rays + ri)[0];
+                    const float4 rd = reinterpret_cast<const float4 *>(rays + ri)[1];
                     if constexpr (ANY) any_begin(st, ro, rd, stack, any_exact);
                     else ordered_begin(st, ro, rd, stack);
-                    my_ray = idx;
+                    my_ray = ri;
                 }
             }
             pos += (uint32_t)__popcll(m);
@@ -591,9 +594,10 @@ __device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, co
                                                         pt_hit *hits, uint32_t n, bool fixup,
                                                         int refill, int leaf_lanes, int32_t *stack,
                                                         unsigned int *tie_count,
-                                                        DeviceTraceCounters *work) {
+                                                        DeviceTraceCounters *work,
+                                                        const uint32_t *perm = nullptr) {
     persistent_traverse<COUNT, false>(s, rays, n, fixup, refill, leaf_lanes, stack, tie_count, work,
-                                      HitSink{hits});
+                                      HitSink{hits}, perm);
 }
 
 // Compacting append to a queue: every lane with `keep` gets a distinct slot.  One atomic

@@ -1,6 +1,9 @@
 // Stand-alone ray/scene intersection kernels (pt_trace_closest*, pt_trace_any*).
 // The per-ray traversal code lives in pt_traverse.h.
 #include "pt_traverse.h"
+#include "internal.h"
+
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 
@@ -67,10 +70,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_ordered_persistent(DeviceScene
                                                                     const pt_ray *rays,
                                                                     pt_hit *hits, uint32_t n,
                                                                     bool fixup, int refill, int leaf_lanes,
-                                                                    DeviceTraceCounters *counters) {
+                                                                    DeviceTraceCounters *counters,
+                                                                    const uint32_t *perm) {
     __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];   // + the bottom sentinel
     persistent_closest_hits<COUNT>(s, rays, hits, n, fixup, refill, leaf_lanes, s_stack + threadIdx.x,
-                                   &counters->tie_count, counters);
+                                   &counters->tie_count, counters, perm);
 }
 
 // IntersectSceneAny, shaders/RadeonRays/bvh.glslh:378-414 (leaf test :350-375, :289-310).
@@ -85,6 +89,35 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene s, const pt_ra
     const bool occ = wide ? occluded_wide(s, ro, rd, s_stack + threadIdx.x)
                           : occluded_skiplink(s, ro, rd);
     occluded[i] = occ ? 1 : 0;
+}
+
+// Sort key of a ray: 30-bit Morton code of its origin's cell in a 1024^3 grid over the scene's
+// root box.  Rays that start close together walk the same part of the tree; on scenes much
+// larger than the caches that is worth more than the sort costs.
+__device__ __forceinline__ unsigned int spread10(unsigned int v) {
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ __launch_bounds__(kBlock) void k_ray_keys(DeviceScene s, const pt_ray *rays, uint32_t n,
+                                                     unsigned int *keys, uint32_t *vals) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 lo = s.nodes[0], hi = s.nodes[1];
+    const float4 o = reinterpret_cast<const float4 *>(rays + i)[0];
+    const float p[3] = {o.x, o.y, o.z}, a[3] = {lo.x, lo.y, lo.z}, b[3] = {hi.x, hi.y, hi.z};
+    unsigned int q[3];
+    for (int k = 0; k < 3; ++k) {
+        const float ext = b[k] - a[k];
+        float x = ext > 0.f ? (p[k] - a[k]) / ext : 0.f;
+        x = fminf(fmaxf(x * 1024.f, 0.f), 1023.f);      // NaN -> 0
+        q[k] = (unsigned int)x;
+    }
+    keys[i] = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+    vals[i] = i;
 }
 
 inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kBlock - 1) / kBlock); }
@@ -126,9 +159,28 @@ void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *r
 
 void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                           uint64_t n, bool fixup, DeviceTraceCounters *counters,
-                          bool count_work, const ExtendConfig &cfg) {
+                          bool count_work, const ExtendConfig &cfg, DeviceBuffer *sort_scratch) {
     if (n == 0) return;
     if (cfg.persistent_blocks > 0) {
+        const uint32_t *perm = nullptr;
+        if (cfg.sort_rays && sort_scratch) {
+            size_t sort_bytes = 0;
+            hipError_t e = hipcub::DeviceRadixSort::SortPairs(
+                nullptr, sort_bytes, (unsigned int *)nullptr, (unsigned int *)nullptr,
+                (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 30, st);
+            const size_t arr = (4 * (size_t)n + 255) / 256 * 256;
+            if (e == hipSuccess && sort_scratch->reserve(4 * arr + sort_bytes) == PT_OK) {
+                char *base = (char *)sort_scratch->ptr;
+                unsigned int *k0 = (unsigned int *)base, *k1 = (unsigned int *)(base + arr);
+                uint32_t *v0 = (uint32_t *)(base + 2 * arr), *v1 = (uint32_t *)(base + 3 * arr);
+                hipLaunchKernelGGL(k_ray_keys, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays,
+                                   (uint32_t)n, k0, v0);
+                e = hipcub::DeviceRadixSort::SortPairs(base + 4 * arr, sort_bytes, k0, k1, v0, v1,
+                                                       (int)n, 0, 30, st);
+                if (e == hipSuccess) perm = v1;
+            }
+            // on any failure the rays are simply taken in queue order
+        }
         static int occ[2] = {0, 0};
         const void *k = count_work ? (const void *)k_trace_ordered_persistent<true>
                                    : (const void *)k_trace_ordered_persistent<false>;
@@ -136,10 +188,10 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
             grid_for(n), persistent_grid(k, kBlock, cfg, &occ[count_work ? 1 : 0]));
         if (count_work)
             hipLaunchKernelGGL((k_trace_ordered_persistent<true>), dim3(grid), dim3(kBlock), 0, st,
-                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, counters);
+                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, counters, perm);
         else
             hipLaunchKernelGGL((k_trace_ordered_persistent<false>), dim3(grid), dim3(kBlock), 0, st,
-                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, counters);
+                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, counters, perm);
         return;
     }
     const unsigned int grid = grid_for(n);

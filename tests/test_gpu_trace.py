@@ -270,3 +270,23 @@ def test_sponza_class_scene_primary_and_secondary(mipt, oracle, scenes, gpu_ctx)
               f"ties {st.tie_rays}")
     finally:
         sc.close()
+
+
+def test_origin_cell_order_does_not_change_hits(mipt, oracle, scenes, gpu_ctx):
+    """trace.sort_rays=1 takes the rays in Morton order of their origins (a locality aid for
+    scenes beyond the caches); every hit lands at its ray's own index, unchanged."""
+    vtx, idx, _, _ = scenes.random_soup(20000, seed=31)
+    nodes = _build(mipt, vtx, idx)
+    rays = random_rays(100003, 17, dtype=mipt.ray_dtype)           # not a multiple of 64
+    rays["o"][5, 0] = np.nan                                        # a NaN origin sorts somewhere, too
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx)
+    try:
+        want = oracle.closest(nodes, vtx, idx, rays, nthreads=8)
+        gpu_ctx.set_option("trace.sort_rays", 1)
+        try:
+            got = sc.trace_closest(rays)
+        finally:
+            gpu_ctx.set_option("trace.sort_rays", -1)
+        assert len(same_hits(got, want, nan_equal=True)) == 0
+    finally:
+        sc.close()

@@ -113,9 +113,15 @@ def lucy(ctx):
     d_h = torch.empty_like(d_r)
     stc = sc.trace_closest_device_counted(d_r.data_ptr(), n, d_h.data_ptr())
     dt = timed(lambda: sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr()), ctx, 5)
+    ref = d_h.clone()
+    ctx.set_option("trace.sort_rays", 0)
+    dt_unsorted = timed(lambda: sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr()), ctx, 5)
+    ctx.set_option("trace.sort_rays", -1)
+    assert torch.equal(ref.view(torch.int32), d_h.view(torch.int32))
     hits = d_h.view(torch.int32)[:, 1]
     return {"config": "Lucy-class stand-in, secondary rays only", "tris": int(idx.shape[0]),
             "nodes": int(nodes.shape[0]), "bvh_build_s": bs, "rays": n, "mrays_s": n / dt / 1e6,
+            "mrays_s_queue_order": n / dt_unsorted / 1e6,
             "hit_fraction": float((hits >= 0).float().mean().item()),
             "box_tests_per_ray": stc.box_tests / n, "tri_tests_per_ray": stc.tri_tests / n,
             "ties": stc.tie_rays}
