@@ -123,6 +123,8 @@ def main():
     ctx.set_kernel_timing(True)
     for k in range(args.warmup):
         mipt.render(ctx, scene, cam, params(1000 + k), film, stats=True)
+    if args.warmup:
+        assemble()                # the collective's first call sets up its channels: not timed
     film.clear()
     torch.cuda.synchronize()
     if world > 1:
@@ -241,7 +243,17 @@ def cpu_baseline(args, nodes, vtx, idx, mats, mids, sky):
     t1 = time.perf_counter()
     _, rays1 = oracle.render(nodes, vtx, idx, mats, mids, scenes.atrium_camera(w1 / h1), p1, nthreads=1)
     dt1 = time.perf_counter() - t1
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model,
             "single_core_value": rays1 / dt1 / 1e6,
             "single_core_sample": "one step at %dx%d: %d rays in %.1f s" % (w1, h1, rays1, dt1),
             "sample": "%d steps of the same frame at %dx%d (1/%d of the pixels), %d spp each, depth %d: "
