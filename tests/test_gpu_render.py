@@ -226,3 +226,40 @@ def test_film_checkpoint_resume_and_image(mipt, scenes, gpu_ctx, tmp_path):
             x.close()
     finally:
         sc.close()
+
+
+def test_cpp_host_program_matches_the_binding(mipt, oracle, scenes, gpu_ctx, tmp_path):
+    """examples/ptrender.cpp drives the C ABI from C++ the way the reference's application
+    would (OBJ -> BVH -> scene -> render -> image); its film equals the Python binding's, both
+    for the host SAH build and (against the CPU restatement on the read-back tree) the GPU build."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "..", "gpu-pathtracer_amd", "ptrender")
+    if not os.path.exists(exe):
+        pytest.fail("gpu-pathtracer_amd/ptrender is not built (make -C gpu-pathtracer_amd ptrender)")
+    obj = os.path.join(here, "golden", "cornell_box.obj")
+    W, H = 96, 64
+    raw, ppm = str(tmp_path / "f.raw"), str(tmp_path / "o.ppm")
+    out = subprocess.run([exe, obj, ppm, "--size", str(W), str(H), "--spp", "5", "--depth", "4", "--nee",
+                          "--seed", "9", "--film", raw], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "32 triangles" in out.stdout
+    got = np.fromfile(raw, dtype=np.float32).reshape(H, W, 4)
+    vtx, idx, mats, mids = scenes.cornell_box()
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx),
+                           mipt.bvh_options(**{"bvh.builder": "sah", "mipt.link_encoding": "int"}))
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx, mats, mids, link_encoding=mipt.PT_LINKS_INT_BITS)
+    film = mipt.Film(gpu_ctx, W, H)
+    try:
+        cam = cornell_camera(mipt, W / H)
+        p = mipt.render_params(W, H, sample_count=5, max_depth=4, seed=9, flags=mipt.PT_RENDER_NEE)
+        mipt.render(gpu_ctx, sc, cam, p, film)
+        np.testing.assert_array_equal(got.view(np.uint32), film.read().view(np.uint32))
+    finally:
+        film.close()
+        sc.close()
+    assert open(ppm, "rb").read().startswith(b"P6\n96 64\n255\n")
+    out = subprocess.run([exe, obj, ppm, "--size", str(W), str(H), "--spp", "2", "--gpu-build"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
