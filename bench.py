@@ -3,7 +3,7 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2], the one the headline metric is quoted on): Sponza-class
+Workload (the configuration the headline metric is quoted on): Sponza-class
 scene (262,144-triangle procedural stand-in for Crytek Sponza, seed 42 -- no assets exist
 offline), 1920x1080, Lambert+GGX materials, max depth 8, Russian roulette from bounce 3.
 A step is one pass of the whole hot path -- raygen, (extend, shade) x depth, accumulate --

@@ -1,8 +1,7 @@
-"""Runs the other BASELINE.json configurations at full size on one GPU and prints one JSON
-line each (bench.py covers configs[2], the headline).  Not part of the driver contract; the
-numbers go into BASELINE.md / DESIGN.md.
+"""Runs the benchmark configurations other than the headline one (which bench.py covers) at
+full size on one GPU, and the BVH-build comparison, printing one JSON line each.
 
-    python tools/bench_configs.py [cornell256 cornell1080 sanmiguel lucy]
+    python tools/bench_configs.py [cornell256 cornell1080 sanmiguel lucy gpubuild]
 """
 import json
 import os
