@@ -30,6 +30,12 @@
 
 namespace mipt {
 
+// Minimum resident waves per SIMD the persistent traversal kernels are compiled for (second
+// argument of __launch_bounds__): bounds their VGPR allocation.
+#ifndef PT_EXTEND_MIN_WAVES
+#define PT_EXTEND_MIN_WAVES 1
+#endif
+
 constexpr int kTraceBlock = PT_TRACE_BLOCK;
 constexpr int kTraceStack = PT_LDS_STACK_ENTRIES;
 constexpr int32_t kSentinel = INT_MIN;

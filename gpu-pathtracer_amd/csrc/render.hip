@@ -23,12 +23,6 @@ namespace {
 
 constexpr int kBlock = kTraceBlock;
 
-// Minimum resident waves per SIMD the closest-hit kernels are compiled for (second
-// argument of __launch_bounds__): bounds their VGPR allocation.
-#ifndef PT_EXTEND_MIN_WAVES
-#define PT_EXTEND_MIN_WAVES 1
-#endif
-
 constexpr int kWideBlock = 1024;   // raygen / shade: 16 waves share one queue atomic
 
 __global__ __launch_bounds__(kWideBlock) void k_pt_raygen(RenderLaunch rl, RenderWorkspace ws,

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_ordered(DeviceScene s, const p
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace_ordered_persistent(DeviceScene s,
+__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_ordered_persistent(DeviceScene s,
                                                                     const pt_ray *rays,
                                                                     pt_hit *hits, uint32_t n,
                                                                     bool fixup, int refill, int leaf_lanes,
