@@ -207,17 +207,18 @@ int pt_bvh_validate(const pt_bbox *nodes, uint32_t n_nodes, uint32_t link_encodi
     BvhTree t;
     tree_from_skip_links(nodes, n_nodes, link_encoding, n_tri, t);
     if (n_tri) {
-        if (t.n_prims != n_tri)
+        // A tree built with spatial splits holds a triangle in several leaves; none may be
+        // missing.
+        if (t.n_prims < n_tri)
             return fail(PT_ERR_INVALID, "skip-link array: " + std::to_string(t.n_prims) +
                                             " leaves for " + std::to_string(n_tri) + " triangles");
         std::vector<uint8_t> seen(n_tri, 0);
         for (size_t i = 0; i < t.size(); ++i)
-            if (t.prim[i] >= 0) {
-                if (seen[(size_t)t.prim[i]])
-                    return fail(PT_ERR_INVALID, "skip-link array: triangle " +
-                                                    std::to_string(t.prim[i]) + " in two leaves");
-                seen[(size_t)t.prim[i]] = 1;
-            }
+            if (t.prim[i] >= 0) seen[(size_t)t.prim[i]] = 1;
+        for (uint32_t k = 0; k < n_tri; ++k)
+            if (!seen[k])
+                return fail(PT_ERR_INVALID,
+                            "skip-link array: triangle " + std::to_string(k) + " is in no leaf");
     }
     return PT_OK;
     PT_CATCH
@@ -330,18 +331,18 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     HIP_CHECK(hipSetDevice(ctx->device));
     BvhTree tree;
     tree_from_skip_links(nodes, n_nodes, link_encoding, n_tri, tree);
-    if (tree.n_prims != n_tri)
+    if (tree.n_prims < n_tri)
         return fail(PT_ERR_INVALID, "pt_scene_create: " + std::to_string(tree.n_prims) +
                                         " leaves for " + std::to_string(n_tri) + " triangles");
     {
+        // Several leaves may hold one triangle (spatial splits); every triangle must be held.
         std::vector<uint8_t> seen(n_tri, 0);
         for (size_t i = 0; i < tree.size(); ++i)
-            if (tree.prim[i] >= 0) {
-                if (seen[(size_t)tree.prim[i]])
-                    return fail(PT_ERR_INVALID, "pt_scene_create: triangle " +
-                                                    std::to_string(tree.prim[i]) + " in two leaves");
-                seen[(size_t)tree.prim[i]] = 1;
-            }
+            if (tree.prim[i] >= 0) seen[(size_t)tree.prim[i]] = 1;
+        for (uint32_t k = 0; k < n_tri; ++k)
+            if (!seen[k])
+                return fail(PT_ERR_INVALID,
+                            "pt_scene_create: triangle " + std::to_string(k) + " is in no leaf");
     }
     for (uint64_t i = 0; i < 3ull * n_tri; ++i)
         if (idx[i] < 0 || (uint32_t)idx[i] >= n_vtx)

@@ -201,9 +201,9 @@ __device__ __forceinline__ void traverse_ordered(const DeviceScene &s, const flo
                     tbest = ht; b0 = h0; b1 = h1; b2 = h2;
                     primid = __float_as_int(q2.y);
                     bound = fminf(tbest + tbest * PT_TIE_WINDOW, tmax);
-                } else {
+                } else if (__float_as_int(q2.y) != primid) {
                     second = fminf(second, ht);
-                }
+                }   // else: another leaf of the same triangle (a tree built with spatial splits)
             }
             if (sp > 0) {
                 --sp;
@@ -347,7 +347,9 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
             const bool bad = hit & !(ht == ht);
             const bool had = st.primid >= 0;
             const bool closer = hit & !bad & (!had | (ht < st.tbest));
-            const bool farther = hit & !bad & !closer;
+            // another leaf of the triangle already held (a tree built with spatial splits) is no
+            // competing candidate
+            const bool farther = hit & !bad & !closer & (__float_as_int(q2.y) != st.primid);
             const float s_old = fminf(st.second, st.tbest), s_new = fminf(st.second, ht);
             st.second = (closer & had) ? s_old : (farther ? s_new : st.second);
             st.tbest = closer ? ht : st.tbest;

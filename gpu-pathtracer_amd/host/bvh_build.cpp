@@ -206,6 +206,242 @@ struct Builder {
     }
 };
 
+// ---- spatial splits -----------------------------------------------------------------------
+// Stands in for RadeonRays::SplitBvh, which the reference selects with bvh.sah.use_splits
+// (src/bvh/bvh_builder.cpp:38-44) and which, like Bvh, is external to the checkout.  The
+// builder is handed boxes only (bvh->Build(bounds, n), :62), so a "split" cuts a primitive's
+// box at a plane into two references to the same primitive (Stich et al. 2009, restricted to
+// boxes): the tree then has more leaves than primitives, each leaf still holding exactly one
+// primitive, as the shader requires.  Options as passed at :43-44: a spatial split is tried
+// down to max_split_depth, when the object split's children overlap by more than min_overlap
+// of the root's area, while fewer than extra_node_budget * n extra references exist.
+struct SplitBuilder {
+    struct Ref {
+        Aabb box;
+        uint32_t prim;
+    };
+    BvhTree *tree;
+    int num_bins;
+    int max_split_depth;
+    float min_overlap;
+    float root_area = 0.f;
+    size_t extra_left = 0;      // references that may still be added
+
+    static float center(const Aabb &b, int k) { return 0.5f * (b.lo[k] + b.hi[k]); }
+
+    uint32_t new_node() {
+        tree->bounds.push_back(pt_bbox{});
+        tree->right.push_back(-1);
+        tree->prim.push_back(-1);
+        return (uint32_t)(tree->bounds.size() - 1);
+    }
+    void set_box(uint32_t node, const Aabb &b) {
+        pt_bbox &o = tree->bounds[node];
+        for (int k = 0; k < 3; ++k) {
+            o.pmin[k] = b.lo[k];
+            o.pmax[k] = b.hi[k];
+        }
+        o.pmin[3] = o.pmax[3] = 0.f;
+    }
+
+    struct ObjectSplit { float cost = FLT_MAX; int axis = -1; int bin = -1; float scale = 0.f; float lo = 0.f; float overlap = 0.f; };
+    struct SpatialSplit { float cost = FLT_MAX; int axis = -1; float plane = 0.f; uint32_t nl = 0, nr = 0; };
+
+    ObjectSplit find_object_split(const std::vector<Ref> &refs, const Aabb &cb) const {
+        ObjectSplit best;
+        const uint32_t n = (uint32_t)refs.size();
+        const int nb = num_bins;
+        std::vector<Aabb> bin_box((size_t)nb), right_box((size_t)nb);
+        std::vector<uint32_t> bin_cnt((size_t)nb);
+        for (int a = 0; a < 3; ++a) {
+            const float ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0.f)) continue;
+            const float scale = (float)nb / ext;
+            for (int b = 0; b < nb; ++b) {
+                bin_box[b].clear();
+                bin_cnt[b] = 0;
+            }
+            for (const Ref &r : refs) {
+                int b = (int)(scale * (center(r.box, a) - cb.lo[a]));
+                b = std::min(std::max(b, 0), nb - 1);
+                bin_cnt[b]++;
+                bin_box[b].grow(r.box);
+            }
+            Aabb acc;
+            acc.clear();
+            for (int b = nb - 1; b > 0; --b) {
+                acc.grow(bin_box[b]);
+                right_box[b] = acc;
+            }
+            acc.clear();
+            uint32_t lc = 0;
+            for (int b = 0; b < nb - 1; ++b) {
+                acc.grow(bin_box[b]);
+                lc += bin_cnt[b];
+                const uint32_t rc = n - lc;
+                if (lc == 0 || rc == 0) continue;
+                const Aabb &rb = right_box[b + 1];
+                const float cost = (float)lc * acc.half_area() + (float)rc * rb.half_area();
+                if (cost < best.cost) {
+                    best.cost = cost;
+                    best.axis = a;
+                    best.bin = b;
+                    best.scale = scale;
+                    best.lo = cb.lo[a];
+                    Aabb ov;                                  // intersection of the two sides
+                    bool empty = false;
+                    for (int k = 0; k < 3; ++k) {
+                        ov.lo[k] = std::fmax(acc.lo[k], rb.lo[k]);
+                        ov.hi[k] = std::fmin(acc.hi[k], rb.hi[k]);
+                        if (!(ov.lo[k] <= ov.hi[k])) empty = true;
+                    }
+                    best.overlap = empty ? 0.f : ov.half_area();
+                }
+            }
+        }
+        return best;
+    }
+
+    SpatialSplit find_spatial_split(const std::vector<Ref> &refs, const Aabb &nbx) const {
+        SpatialSplit best;
+        const uint32_t n = (uint32_t)refs.size();
+        const int nb = num_bins;
+        std::vector<Aabb> bin_box((size_t)nb), right_box((size_t)nb);
+        std::vector<uint32_t> enter((size_t)nb), leave((size_t)nb);
+        for (int a = 0; a < 3; ++a) {
+            const float lo = nbx.lo[a], ext = nbx.hi[a] - lo;
+            if (!(ext > 0.f)) continue;
+            const float scale = (float)nb / ext, width = ext / (float)nb;
+            for (int b = 0; b < nb; ++b) {
+                bin_box[b].clear();
+                enter[b] = leave[b] = 0;
+            }
+            for (const Ref &r : refs) {
+                int b0 = std::min(std::max((int)(scale * (r.box.lo[a] - lo)), 0), nb - 1);
+                int b1 = std::min(std::max((int)(scale * (r.box.hi[a] - lo)), b0), nb - 1);
+                enter[b0]++;
+                leave[b1]++;
+                for (int b = b0; b <= b1; ++b) {          // the box clipped to the bin's slab
+                    Aabb c = r.box;
+                    if (b > b0) c.lo[a] = std::fmax(c.lo[a], lo + width * (float)b);
+                    if (b < b1) c.hi[a] = std::fmin(c.hi[a], lo + width * (float)(b + 1));
+                    bin_box[b].grow(c);
+                }
+            }
+            Aabb acc;
+            acc.clear();
+            for (int b = nb - 1; b > 0; --b) {
+                acc.grow(bin_box[b]);
+                right_box[b] = acc;
+            }
+            acc.clear();
+            uint32_t nl = 0, nr = n;
+            for (int b = 0; b < nb - 1; ++b) {
+                acc.grow(bin_box[b]);
+                nl += enter[b];
+                nr -= leave[b];
+                // a plane that leaves every reference on one side makes no progress
+                if (nl == 0 || nr == 0 || nl >= n || nr >= n) continue;
+                const float cost = (float)nl * acc.half_area() + (float)nr * right_box[b + 1].half_area();
+                if (cost < best.cost) {
+                    best.cost = cost;
+                    best.axis = a;
+                    best.plane = lo + width * (float)(b + 1);
+                    best.nl = nl;
+                    best.nr = nr;
+                }
+            }
+        }
+        return best;
+    }
+
+    void build(std::vector<Ref> &refs, int depth) {
+        const uint32_t node = new_node();
+        const uint32_t n = (uint32_t)refs.size();
+        Aabb nbx, cb;
+        nbx.clear();
+        cb.clear();
+        for (const Ref &r : refs) {
+            nbx.grow(r.box);
+            const float c[3] = {center(r.box, 0), center(r.box, 1), center(r.box, 2)};
+            cb.grow_point(c);
+        }
+        set_box(node, nbx);
+        if (n == 1) {
+            tree->prim[node] = (int32_t)refs[0].prim;
+            return;
+        }
+        const ObjectSplit os = n > 2 ? find_object_split(refs, cb) : ObjectSplit{};
+        SpatialSplit ss;
+        if (depth < max_split_depth && extra_left > 0 && os.axis >= 0 && root_area > 0.f &&
+            os.overlap / root_area > min_overlap)
+            ss = find_spatial_split(refs, nbx);
+        std::vector<Ref> left, right;
+        bool done = false;
+        if (ss.axis >= 0 && ss.cost < os.cost) {
+            const int a = ss.axis;
+            size_t straddle = 0;
+            for (const Ref &r : refs)
+                if (r.box.lo[a] < ss.plane && r.box.hi[a] > ss.plane) ++straddle;
+            if (straddle <= extra_left) {
+                for (const Ref &r : refs) {
+                    if (r.box.hi[a] <= ss.plane && r.box.lo[a] < ss.plane) {
+                        left.push_back(r);
+                    } else if (r.box.lo[a] >= ss.plane) {
+                        right.push_back(r);
+                    } else {                                   // cut the box at the plane
+                        Ref l = r, rr = r;
+                        l.box.hi[a] = ss.plane;
+                        rr.box.lo[a] = ss.plane;
+                        left.push_back(l);
+                        right.push_back(rr);
+                    }
+                }
+                if (!left.empty() && !right.empty() && left.size() < n && right.size() < n) {
+                    extra_left -= straddle;
+                    done = true;
+                } else {
+                    left.clear();
+                    right.clear();
+                }
+            }
+        }
+        if (!done && os.axis >= 0) {
+            const int nbm1 = num_bins - 1;
+            for (const Ref &r : refs) {
+                int b = (int)(os.scale * (center(r.box, os.axis) - os.lo));
+                b = std::min(std::max(b, 0), nbm1);
+                (b <= os.bin ? left : right).push_back(r);
+            }
+            done = !left.empty() && !right.empty();
+            if (!done) {
+                left.clear();
+                right.clear();
+            }
+        }
+        if (!done) {
+            // No usable plane (two references, or coincident centres): order by centre on the
+            // longest axis, then by primitive and box, and cut in the middle.
+            int axis = 0;
+            const float e[3] = {cb.hi[0] - cb.lo[0], cb.hi[1] - cb.lo[1], cb.hi[2] - cb.lo[2]};
+            if (e[1] > e[axis]) axis = 1;
+            if (e[2] > e[axis]) axis = 2;
+            std::stable_sort(refs.begin(), refs.end(), [&](const Ref &x, const Ref &y) {
+                const float cx = center(x.box, axis), cy = center(y.box, axis);
+                return cx < cy || (cx == cy && x.prim < y.prim);
+            });
+            left.assign(refs.begin(), refs.begin() + n / 2);
+            right.assign(refs.begin() + n / 2, refs.end());
+        }
+        refs.clear();
+        refs.shrink_to_fit();
+        build(left, depth + 1);
+        left = std::vector<Ref>();
+        tree->right[node] = (int32_t)tree->bounds.size();
+        build(right, depth + 1);
+    }
+};
+
 } // namespace
 
 void inflate_leaf_bounds(pt_bbox *boxes, uint32_t n) {
@@ -243,9 +479,6 @@ void mesh_leaf_bounds(const float *vtx, const int32_t *idx, uint32_t n_tri, pt_b
 void build_tree(const pt_bbox *leaf_bounds, uint32_t n, const pt_bvh_options &opt, BvhTree &out) {
     if (n == 0) throw std::runtime_error("pt_bvh_build: no primitives");
     if (n > (1u << 30)) throw std::runtime_error("pt_bvh_build: too many primitives");
-    if (opt.use_splits)
-        throw std::runtime_error(
-            "pt_bvh_build: bvh.sah.use_splits (spatial splits) is not implemented");
     if (opt.num_bins < 2 || opt.num_bins > 4096)
         throw std::runtime_error("pt_bvh_build: bvh.sah.num_bins out of range [2,4096]");
     for (uint32_t i = 0; i < n; ++i)
@@ -254,6 +487,39 @@ void build_tree(const pt_bbox *leaf_bounds, uint32_t n, const pt_bvh_options &op
                 !std::isfinite(leaf_bounds[i].pmin[k]) || !std::isfinite(leaf_bounds[i].pmax[k]))
                 throw std::runtime_error("pt_bvh_build: leaf box " + std::to_string(i) +
                                          " is empty, inverted or not finite");
+
+    if (opt.use_splits) {
+        if (!(opt.extra_node_budget >= 0.f) || !(opt.min_overlap >= 0.f))
+            throw std::runtime_error("pt_bvh_build: bvh.sah.extra_node_budget and "
+                                     "bvh.sah.min_overlap must be >= 0");
+        out.bounds.clear();
+        out.right.clear();
+        out.prim.clear();
+        SplitBuilder sb;
+        sb.tree = &out;
+        sb.num_bins = opt.num_bins;
+        sb.max_split_depth = opt.max_split_depth;
+        sb.min_overlap = opt.min_overlap;
+        sb.extra_left = (size_t)((double)opt.extra_node_budget * (double)n);
+        std::vector<SplitBuilder::Ref> refs(n);
+        Aabb root;
+        root.clear();
+        for (uint32_t i = 0; i < n; ++i) {
+            for (int k = 0; k < 3; ++k) {
+                refs[i].box.lo[k] = leaf_bounds[i].pmin[k];
+                refs[i].box.hi[k] = leaf_bounds[i].pmax[k];
+            }
+            refs[i].prim = i;
+            root.grow(refs[i].box);
+        }
+        sb.root_area = root.half_area();
+        out.bounds.reserve(2 * (size_t)n + 2 * sb.extra_left);
+        out.right.reserve(2 * (size_t)n + 2 * sb.extra_left);
+        out.prim.reserve(2 * (size_t)n + 2 * sb.extra_left);
+        sb.build(refs, 0);
+        out.n_prims = (uint32_t)((out.bounds.size() + 1) / 2);      // leaves
+        return;
+    }
 
     const size_t n_nodes = 2 * (size_t)n - 1;
     out.bounds.assign(n_nodes, pt_bbox{});

@@ -137,7 +137,8 @@ int pt_bvh_linearize(const pt_bbox *bounds, const int32_t *left, const int32_t *
                      pt_bbox *out_nodes);
 
 /* Checks every structural property of a skip-link array (pre-order, left child adjacent,
- * links, one leaf per triangle, child boxes inside parents' boxes is NOT required). */
+ * links, one triangle per leaf and every triangle in at least one leaf -- several with
+ * spatial splits; child boxes inside parents' boxes is NOT required). */
 int pt_bvh_validate(const pt_bbox *nodes, uint32_t n_nodes, uint32_t link_encoding,
                     uint32_t n_tri);
 

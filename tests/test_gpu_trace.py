@@ -290,3 +290,32 @@ def test_origin_cell_order_does_not_change_hits(mipt, oracle, scenes, gpu_ctx):
         assert len(same_hits(got, want, nan_equal=True)) == 0
     finally:
         sc.close()
+
+
+def test_tree_with_spatial_splits_on_device(mipt, oracle, scenes, gpu_ctx):
+    """A triangle held by several leaves (bvh.sah.use_splits): same hits as the oracle on that
+    array, and its second leaf is not mistaken for a competing candidate (no re-resolution)."""
+    from test_host_bvh import _sliver_scene
+    vtx, idx = _sliver_scene(scenes, n=6000, seed=4)
+    lb = mipt.mesh_leaf_bounds(vtx, idx)
+    nodes = mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": "sah", "bvh.sah.use_splits": 1,
+                                                   "bvh.sah.max_split_depth": 16,
+                                                   "bvh.sah.min_overlap": 1e-4}))
+    assert (nodes.shape[0] + 1) // 2 > idx.shape[0]
+    rays = random_rays(100000, 23, dtype=mipt.ray_dtype)
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx)
+    try:
+        got, st = sc.trace_closest(rays, stats=True)
+        want = oracle.closest(nodes, vtx, idx, rays, nthreads=8)
+        assert len(same_hits(got, want)) == 0
+        assert st.tie_rays < 20
+        gpu_ctx.set_option("extend.persistent", 0)              # the per-thread loop, too
+        try:
+            got2, st2 = sc.trace_closest(rays, stats=True)
+        finally:
+            gpu_ctx.set_option("extend.persistent", 1)
+        assert len(same_hits(got2, want)) == 0 and st2.tie_rays < 20
+        rays["o"][:, 3] = 7.0
+        np.testing.assert_array_equal(sc.trace_any(rays), oracle.any_hit(nodes, vtx, idx, rays, nthreads=8))
+    finally:
+        sc.close()

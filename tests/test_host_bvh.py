@@ -215,3 +215,58 @@ def test_bvh_cache_round_trip(mipt, scenes, tmp_path):
     d, cached = mipt.build_bvh_cached(lb, path, mipt.bvh_options(**{"bvh.builder": "median"}))
     assert not cached
     np.testing.assert_array_equal(c.view(np.uint32), d.view(np.uint32))
+
+
+def _sliver_scene(scenes, n=1500, seed=13):
+    """Small triangles plus long thin ones whose boxes span much of the scene: what spatial
+    splits are for."""
+    vtx, idx, _, _ = scenes.random_soup(n, seed=seed, extent=10.0, size=0.3)
+    rng = np.random.default_rng(seed)
+    m = n // 10
+    a = rng.uniform(-10, 10, size=(m, 3))
+    d = rng.normal(size=(m, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    b = a + d * rng.uniform(8, 20, size=(m, 1))
+    c = a + rng.normal(size=(m, 3)) * 0.1
+    long_v = np.stack([a, b, c], axis=1).reshape(-1, 3).astype(np.float32)
+    vtx = np.concatenate([vtx, long_v])
+    idx = np.concatenate([idx, np.arange(3 * m, dtype=np.int32).reshape(-1, 3) + 3 * n])
+    return vtx, idx
+
+
+def test_spatial_splits(mipt, oracle, scenes):
+    """bvh.sah.use_splits (src/bvh/bvh_builder.cpp:38-44): boxes are cut, so a triangle may sit
+    in several leaves; the array stays a valid skip-link tree, the nearest hit stays that of the
+    linear scan, and rays test fewer boxes on a scene with slivers."""
+    vtx, idx = _sliver_scene(scenes)
+    T = idx.shape[0]
+    lb = mipt.mesh_leaf_bounds(vtx, idx)
+    plain = mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": "sah"}))
+    split = mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": "sah", "bvh.sah.use_splits": 1,
+                                                   "bvh.sah.max_split_depth": 16,
+                                                   "bvh.sah.min_overlap": 1e-4}))
+    assert plain.shape[0] == 2 * T - 1
+    leaves = (split.shape[0] + 1) // 2
+    assert T < leaves <= T + int(0.5 * T)                      # extra_node_budget = 0.5
+    mipt.validate_bvh(split, T)
+    raw = split.view(np.float32).reshape(-1, 8)
+    payload = raw[:, 3].astype(np.int64)
+    assert set(payload[payload >= 0].tolist()) == set(range(T))
+    # a leaf's box lies inside its triangle's inflated box
+    full = oracle.inflate(lb).view(np.float32).reshape(-1, 8)
+    lf = payload >= 0
+    assert (raw[lf, 0:3] >= full[payload[lf], 0:3]).all() and (raw[lf, 4:7] <= full[payload[lf], 4:7]).all()
+    rays = random_rays(20000, 5, dtype=oracle.ray_dtype)
+    got, c_split = oracle.closest(split, vtx, idx, rays, nthreads=8, counters=True)
+    want, c_plain = oracle.closest(plain, vtx, idx, rays, nthreads=8, counters=True)
+    brute = oracle.brute_closest(vtx, idx, rays, nthreads=8)
+    np.testing.assert_array_equal(got["uvwt"][:, 3], brute["uvwt"][:, 3])
+    np.testing.assert_array_equal(got["primid"], want["primid"])
+    # boxes are cut, not re-fitted to the geometry (the builder is given boxes only), so the gain
+    # is modest: fewer slab tests, somewhat more triangle tests
+    assert c_split.box_tests < c_plain.box_tests
+    # budget 0: no splits, the plain tree
+    none = mipt.build_bvh(lb, mipt.bvh_options(**{"bvh.builder": "sah", "bvh.sah.use_splits": 1,
+                                                  "bvh.sah.extra_node_budget": 0}))
+    assert none.shape[0] == 2 * T - 1
+    mipt.validate_bvh(none, T)
