@@ -34,7 +34,7 @@ struct pt_context {
     int extend_persistent = 1;      // option "extend.persistent"
     int extend_refill = 24;         // option "extend.refill"
     int extend_leaf_lanes = 16;     // option "extend.leaf_lanes"
-    int extend_blocks_per_cu = 6;   // option "extend.blocks_per_cu"
+    int extend_blocks_per_cu = 5;   // option "extend.blocks_per_cu"
     int any_exact_order = 0;        // option "any.exact_order"
     int trace_sort_rays = -1;       // option "trace.sort_rays": 0 off, 1 on, -1 by scene size
     mipt::DeviceTraceCounters *counters = nullptr;

@@ -177,7 +177,7 @@ int pt_context_set_kernel_timing(pt_context *ctx, int on);
  * "extend.refill" 1..64: idle lanes that trigger a refill (default 24);
  * "extend.leaf_lanes" 1..64: lanes waiting at a triangle that trigger a triangle step of the
  * wave (default 16); "extend.blocks_per_cu" 1..8: persistent workgroups per compute unit
- * (default 6); "any.exact_order" 0|1: occlusion queries walk the reference's skip links
+ * (default 5); "any.exact_order" 0|1: occlusion queries walk the reference's skip links
  * instead of the two-child nodes (default 0); "trace.sort_rays" -1|0|1: pt_trace_closest*
  * takes the rays in Morton order of their origins (default -1: when the scene exceeds the
  * 256 MB Infinity Cache and the call has at least 2^18 rays).  Results do not depend on any
