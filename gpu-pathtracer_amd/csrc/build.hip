@@ -299,6 +299,173 @@ __global__ __launch_bounds__(kB) void k_emit_leaf(EmitArgs a) {
     q[2] = make_float4(v2[2], __int_as_float(a.mat_ids[tri]), 0.f, 0.f);
 }
 
+// ---- the other tree: parallel locally-ordered clustering (Meister & Bittner 2018) -------------
+// Bottom-up: the clusters (at first the Morton-ordered triangles) each look `radius` places
+// to either side for the neighbour whose union with them has the least surface area; pairs
+// that choose each other merge into a new node; the survivors are compacted, order kept, and
+// the round repeats until one cluster is left.  Trees come out close to a full SAH build's.
+//
+// Nodes 0..n-1 are the leaves in Morton order, n.. the inner nodes in creation order (each
+// round's in one block, so a child always has a smaller number than its parent's round).
+// Pairs are ranked by (area, not i^1 == j, |i - j|, min(i, j)): symmetric in the pair and total
+// for one cluster's candidates, so the best-ranked pair of a round is always mutual and every
+// round merges at least once; the i^1 term pairs up clusters with identical boxes instead of
+// merging them one per round.
+struct PlocNodes {
+    float4 *box;        // 2 x float4 per node
+    int32_t *left, *right;
+    uint32_t *size;     // leaves below
+    uint32_t *pos;      // pre-order position
+    uint32_t *before;   // leaves before it in pre-order
+};
+
+__global__ __launch_bounds__(kB) void k_ploc_init(uint32_t n, const uint32_t *vals,
+                                                  const float4 *boxes, PlocNodes t, uint32_t *cl) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t tri = vals[i];
+    t.box[2 * (size_t)i + 0] = boxes[2 * (size_t)tri + 0];
+    t.box[2 * (size_t)i + 1] = boxes[2 * (size_t)tri + 1];
+    t.size[i] = 1;
+    cl[i] = i;
+}
+
+__global__ __launch_bounds__(kB) void k_ploc_nearest(uint32_t m, const uint32_t *cl, PlocNodes t,
+                                                     int radius, uint32_t *nearest) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= (int)m) return;
+    const uint32_t me = cl[i];
+    const float4 alo = t.box[2 * (size_t)me], ahi = t.box[2 * (size_t)me + 1];
+    float best_area = INFINITY;
+    int best_j = -1, best_rank = 0;
+    const int j0 = max(i - radius, 0), j1 = min(i + radius, (int)m - 1);
+    for (int j = j0; j <= j1; ++j) {
+        if (j == i) continue;
+        const uint32_t o = cl[j];
+        const float4 blo = t.box[2 * (size_t)o], bhi = t.box[2 * (size_t)o + 1];
+        const float ex = fmaxf(ahi.x, bhi.x) - fminf(alo.x, blo.x);
+        const float ey = fmaxf(ahi.y, bhi.y) - fminf(alo.y, blo.y);
+        const float ez = fmaxf(ahi.z, bhi.z) - fminf(alo.z, blo.z);
+        const float area = (ex * ey + ex * ez) + ey * ez;
+        // rank of the tie-breaks, smaller is better: buddy, distance, lower index of the pair
+        const int rank = (((i ^ 1) == j ? 0 : 1) << 30) | (abs(i - j) << 1) | (j < i ? 0 : 1);
+        if (best_j < 0 || area < best_area || (area == best_area && rank < best_rank)) {
+            best_area = area;
+            best_j = j;
+            best_rank = rank;
+        }
+    }
+    nearest[i] = (uint32_t)best_j;
+}
+
+// merge[i] = 1 if cluster i starts a merged pair (it and its choice chose each other, i the
+// lower); keep[i] = 0 only for the upper cluster of such a pair.
+__global__ __launch_bounds__(kB) void k_ploc_flags(uint32_t m, const uint32_t *nearest,
+                                                   uint32_t *merge, uint32_t *keep) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t j = nearest[i];
+    const bool mutual = j < m && nearest[j] == i;
+    merge[i] = mutual && i < j;
+    keep[i] = !(mutual && i > j);
+}
+
+__global__ void k_ploc_count(uint32_t m, const uint32_t *merge, const uint32_t *merge_idx,
+                             unsigned int *out) {
+    *out = merge_idx[m - 1] + merge[m - 1];
+}
+
+__global__ __launch_bounds__(kB) void k_ploc_apply(uint32_t m, const uint32_t *cl,
+                                                   const uint32_t *nearest, const uint32_t *merge,
+                                                   const uint32_t *merge_idx, const uint32_t *keep,
+                                                   const uint32_t *new_pos, uint32_t base, PlocNodes t,
+                                                   uint32_t *cl_out) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= m || !keep[i]) return;
+    uint32_t id = cl[i];
+    if (merge[i]) {
+        const uint32_t l = id, r = cl[nearest[i]];
+        id = base + merge_idx[i];
+        const float4 llo = t.box[2 * (size_t)l], lhi = t.box[2 * (size_t)l + 1];
+        const float4 rlo = t.box[2 * (size_t)r], rhi = t.box[2 * (size_t)r + 1];
+        t.box[2 * (size_t)id + 0] = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), 0.f);
+        t.box[2 * (size_t)id + 1] = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.f);
+        t.left[id] = (int32_t)l;
+        t.right[id] = (int32_t)r;
+        t.size[id] = t.size[l] + t.size[r];
+    }
+    cl_out[new_pos[i]] = id;
+}
+
+// Top-down, one round's nodes per launch, last round first: a node hands its children their
+// pre-order position and the number of leaves before them.
+__global__ __launch_bounds__(kB) void k_ploc_place(uint32_t first_id, uint32_t count, PlocNodes t,
+                                                   uint32_t depth_of_round, unsigned int *max_depth) {
+    const uint32_t k = blockIdx.x * kB + threadIdx.x;
+    if (k >= count) return;
+    const uint32_t id = first_id + k;
+    const uint32_t p = t.pos[id], b = t.before[id];
+    const uint32_t l = (uint32_t)t.left[id], r = (uint32_t)t.right[id];
+    t.pos[l] = p + 1;
+    t.before[l] = b;
+    t.pos[r] = p + 2 * t.size[l];
+    t.before[r] = b + t.size[l];
+    (void)depth_of_round;
+    (void)max_depth;
+}
+
+struct PlocEmitArgs {
+    PlocNodes t;
+    const uint32_t *vals;
+    const float *vtx;
+    const int32_t *idx;
+    const int32_t *mat_ids;
+    float4 *nodes, *wnodes, *wtris, *stris;
+    uint32_t n, enc;
+};
+
+__global__ __launch_bounds__(kB) void k_ploc_emit(PlocEmitArgs a) {
+    const uint32_t id = blockIdx.x * kB + threadIdx.x;
+    const uint32_t total = 2 * a.n - 1;
+    if (id >= total) return;
+    const uint32_t pos = a.t.pos[id], before = a.t.before[id];
+    const float4 lo = a.t.box[2 * (size_t)id], hi = a.t.box[2 * (size_t)id + 1];
+    if (id < a.n) {                                      // leaf: Morton position id
+        const uint32_t tri = a.vals[id];
+        a.nodes[2 * (size_t)pos + 0] = make_float4(lo.x, lo.y, lo.z, encode_index((int32_t)tri, a.enc));
+        a.nodes[2 * (size_t)pos + 1] =
+            make_float4(hi.x, hi.y, hi.z, encode_index(pos + 1 < total ? (int32_t)(pos + 1) : -1, a.enc));
+        const int32_t i0 = a.idx[3 * (size_t)tri], i1 = a.idx[3 * (size_t)tri + 1],
+                      i2 = a.idx[3 * (size_t)tri + 2];
+        const float *v0 = a.vtx + 3 * (size_t)i0, *v1 = a.vtx + 3 * (size_t)i1,
+                    *v2 = a.vtx + 3 * (size_t)i2;
+        float4 *r = a.wtris + 3 * (size_t)before;        // leaf slot = leaves before it
+        r[0] = make_float4(v0[0], v0[1], v0[2], v1[0]);
+        r[1] = make_float4(v1[1], v1[2], v2[0], v2[1]);
+        r[2] = make_float4(v2[2], __int_as_float((int32_t)tri), 0.f, 0.f);
+        float4 *q = a.stris + 3 * (size_t)tri;
+        q[0] = r[0];
+        q[1] = r[1];
+        q[2] = make_float4(v2[2], __int_as_float(a.mat_ids[tri]), 0.f, 0.f);
+        return;
+    }
+    const uint32_t next = pos + 2 * a.t.size[id] - 1;
+    a.nodes[2 * (size_t)pos + 0] = make_float4(lo.x, lo.y, lo.z, encode_index(-1, a.enc));
+    a.nodes[2 * (size_t)pos + 1] =
+        make_float4(hi.x, hi.y, hi.z, encode_index(next < total ? (int32_t)next : -1, a.enc));
+    const uint32_t l = (uint32_t)a.t.left[id], r = (uint32_t)a.t.right[id];
+    const float4 lmin = a.t.box[2 * (size_t)l], lmax = a.t.box[2 * (size_t)l + 1];
+    const float4 rmin = a.t.box[2 * (size_t)r], rmax = a.t.box[2 * (size_t)r + 1];
+    // inner nodes are numbered among themselves in pre-order: position minus leaves before
+    const int32_t ref_l = l >= a.n ? (int32_t)(a.t.pos[l] - a.t.before[l]) : ~(int32_t)(3 * a.t.before[l]);
+    const int32_t ref_r = r >= a.n ? (int32_t)(a.t.pos[r] - a.t.before[r]) : ~(int32_t)(3 * a.t.before[r]);
+    float4 *w = a.wnodes + 4 * (size_t)(pos - before);
+    w[0] = make_float4(lmin.x, lmax.x, lmin.y, lmax.y);
+    w[1] = make_float4(rmin.x, rmax.x, rmin.y, rmax.y);
+    w[2] = make_float4(lmin.z, lmax.z, rmin.z, rmax.z);
+    w[3] = make_float4(__int_as_float(ref_l), __int_as_float(ref_r), 0.f, 0.f);
+}
+
 inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kB - 1) / kB); }
 
 #define BUILD_CHECK(expr)                                 \
@@ -316,7 +483,8 @@ inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kB - 1) / 
 DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
                                         uint32_t n, uint32_t enc, DeviceBuffer &scratch,
                                         const int32_t *d_mat_ids, float4 *d_nodes,
-                                        float4 *d_wnodes, float4 *d_wtris, float4 *d_stris) {
+                                        float4 *d_wnodes, float4 *d_wtris, float4 *d_stris,
+                                        int ploc_radius) {
     DeviceBuildResult res;
     const uint32_t n_inner = n - 1;
     // scratch carve-up
@@ -343,7 +511,18 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
     BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort2_bytes, (uint32_t *)nullptr,
                                                    (uint32_t *)nullptr, (uint32_t *)nullptr,
                                                    (uint32_t *)nullptr, (int)n, 0, 8, st));
-    const size_t o_sort = take(std::max(sort_bytes, sort2_bytes));
+    size_t scan_bytes = 0;
+    BUILD_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr,
+                                                 (uint32_t *)nullptr, (int)n, st));
+    const size_t o_sort = take(std::max(std::max(sort_bytes, sort2_bytes), scan_bytes));
+    // clustering only: node arrays for 2n-1 nodes (the other arrays above are reused)
+    const size_t total_nodes = 2 * (size_t)n - 1;
+    const size_t o_pbox = ploc_radius > 0 ? take(32 * total_nodes) : 0;
+    const size_t o_pleft = ploc_radius > 0 ? take(4 * total_nodes) : 0;
+    const size_t o_pright = ploc_radius > 0 ? take(4 * total_nodes) : 0;
+    const size_t o_psize = ploc_radius > 0 ? take(4 * total_nodes) : 0;
+    const size_t o_ppos = ploc_radius > 0 ? take(4 * total_nodes) : 0;
+    const size_t o_pbefore = ploc_radius > 0 ? take(4 * total_nodes) : 0;
     if (scratch.reserve(off) != PT_OK) {
         res.no_memory = true;
         return res;
@@ -373,6 +552,68 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
     hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kB), 0, st, boxes, n, small, k0, v0);
     BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_sort, sort_bytes, k0, k1, v0, v1, (int)n, 0,
                                                    63, st));
+    if (ploc_radius > 0) {
+        PlocNodes t;
+        t.box = (float4 *)(base + o_pbox);
+        t.left = (int32_t *)(base + o_pleft);
+        t.right = (int32_t *)(base + o_pright);
+        t.size = (uint32_t *)(base + o_psize);
+        t.pos = (uint32_t *)(base + o_ppos);
+        t.before = (uint32_t *)(base + o_pbefore);
+        // the radix-tree arrays double as cluster lists, flags and scans
+        uint32_t *cl = (uint32_t *)left, *cl_next = (uint32_t *)right, *nearest = first;
+        uint32_t *merge = last, *keep = iparent, *merge_idx = lparent, *new_pos = depth;
+        hipLaunchKernelGGL(k_ploc_init, dim3(grid_for(n)), dim3(kB), 0, st, n, v1, boxes, t, cl);
+        unsigned int h_small[8];
+        BUILD_CHECK(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, st));
+        BUILD_CHECK(hipStreamSynchronize(st));
+        if (h_small[6]) {
+            res.bad_input = true;
+            return res;
+        }
+        std::vector<uint32_t> round_first, round_count;
+        uint32_t m = n, next_id = n;
+        while (m > 1) {
+            hipLaunchKernelGGL(k_ploc_nearest, dim3(grid_for(m)), dim3(kB), 0, st, m, cl, t,
+                               ploc_radius, nearest);
+            hipLaunchKernelGGL(k_ploc_flags, dim3(grid_for(m)), dim3(kB), 0, st, m, nearest, merge, keep);
+            BUILD_CHECK(hipcub::DeviceScan::ExclusiveSum(base + o_sort, scan_bytes, merge, merge_idx, (int)m, st));
+            BUILD_CHECK(hipcub::DeviceScan::ExclusiveSum(base + o_sort, scan_bytes, keep, new_pos, (int)m, st));
+            hipLaunchKernelGGL(k_ploc_count, dim3(1), dim3(1), 0, st, m, merge, merge_idx, small + 8);
+            hipLaunchKernelGGL(k_ploc_apply, dim3(grid_for(m)), dim3(kB), 0, st, m, cl, nearest, merge,
+                               merge_idx, keep, new_pos, next_id, t, cl_next);
+            unsigned int merges = 0;
+            BUILD_CHECK(hipMemcpyAsync(&merges, small + 8, sizeof(merges), hipMemcpyDeviceToHost, st));
+            BUILD_CHECK(hipStreamSynchronize(st));
+            if (merges == 0 || merges > m / 2) {          // cannot happen (see the ranking above)
+                res.hip_error = hipErrorUnknown;
+                res.what = "clustering round made no progress";
+                return res;
+            }
+            round_first.push_back(next_id);
+            round_count.push_back(merges);
+            next_id += merges;
+            m -= merges;
+            std::swap(cl, cl_next);
+        }
+        // root = the last node made; place everything top-down, then write the outputs
+        const uint32_t root = next_id - 1;
+        const uint32_t zero2[2] = {0u, 0u};
+        BUILD_CHECK(hipMemcpyAsync(t.pos + root, &zero2[0], 4, hipMemcpyHostToDevice, st));
+        BUILD_CHECK(hipMemcpyAsync(t.before + root, &zero2[1], 4, hipMemcpyHostToDevice, st));
+        for (size_t k = round_first.size(); k-- > 0;)
+            hipLaunchKernelGGL(k_ploc_place, dim3(grid_for(round_count[k])), dim3(kB), 0, st,
+                               round_first[k], round_count[k], t, 0u, small + 9);
+        PlocEmitArgs ea;
+        ea.t = t; ea.vals = v1; ea.vtx = d_vtx; ea.idx = d_idx; ea.mat_ids = d_mat_ids;
+        ea.nodes = d_nodes; ea.wnodes = d_wnodes; ea.wtris = d_wtris; ea.stris = d_stris;
+        ea.n = n; ea.enc = enc;
+        hipLaunchKernelGGL(k_ploc_emit, dim3(grid_for(2 * (uint64_t)n - 1)), dim3(kB), 0, st, ea);
+        BUILD_CHECK(hipGetLastError());
+        BUILD_CHECK(hipStreamSynchronize(st));
+        res.max_depth = (uint32_t)round_first.size() + 1;     // a path gains at most one node per round
+        return res;
+    }
     // 4. tree, depths
     hipLaunchKernelGGL(k_radix_tree, dim3(grid_for(n_inner)), dim3(kB), 0, st, k1, (int)n, left, right,
                        first, last, iparent, lparent);

@@ -37,6 +37,7 @@ struct pt_context {
     int extend_blocks_per_cu = 5;   // option "extend.blocks_per_cu"
     int any_exact_order = 0;        // option "any.exact_order"
     int trace_sort_rays = -1;       // option "trace.sort_rays": 0 off, 1 on, -1 by scene size
+    int build_ploc_radius = 0;      // option "build.ploc_radius": 0 = radix tree, else clustering
     mipt::DeviceTraceCounters *counters = nullptr;
     mipt::DeviceBuffer io_rays;     // staging for the host-pointer entry points
     mipt::DeviceBuffer io_hits;

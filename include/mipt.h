@@ -181,7 +181,9 @@ int pt_context_set_kernel_timing(pt_context *ctx, int on);
  * instead of the two-child nodes (default 0); "trace.sort_rays" -1|0|1: pt_trace_closest*
  * takes the rays in Morton order of their origins (default -1: when the scene exceeds the
  * 256 MB Infinity Cache and the call has at least 2^18 rays).  Results do not depend on any
- * of them. */
+ * of them.  "build.ploc_radius" 0..64 selects pt_scene_build's tree: 0 (default) a binary radix
+ * tree over the Morton codes, r > 0 locally-ordered clustering with search radius r (lower
+ * SAH cost, a few times the build time; it changes the tree, not any hit). */
 int pt_context_set_option(pt_context *ctx, const char *key, const char *value);
 int pt_context_destroy(pt_context *ctx);
 
@@ -196,7 +198,8 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
 /* build_mesh_bvh + init_device_data (src/main_granite.cpp:115-194) entirely on the GPU: leaf
  * boxes (:162-172), their inflation (src/bvh/bvh_builder.cpp:53-59, bit-identical to the host
  * path), a linear BVH over the Morton-ordered box centres, the skip-link array in the format
- * of src/bvh/bvh_builder.h:26-34 and the traversal layouts.  Two orders of magnitude faster
+ * of src/bvh/bvh_builder.h:26-34 and the traversal layouts (option "build.ploc_radius"
+ * selects clustering instead of the radix tree).  Two orders of magnitude faster
  * than pt_bvh_build + pt_scene_create on large meshes; the tree is of lower quality than the
  * SAH builder's (more boxes per ray).  The result is deterministic. */
 int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int32_t *idx,

@@ -13,6 +13,14 @@ from conftest import random_rays, same_hits
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[0, 8, 2], ids=["radix_tree", "clustering", "clustering_r2"], autouse=True)
+def algorithm(request, gpu_ctx):
+    """Both GPU builders: the Morton radix tree (the default) and locally-ordered clustering."""
+    gpu_ctx.set_option("build.ploc_radius", request.param)
+    yield request.param
+    gpu_ctx.set_option("build.ploc_radius", 0)
+
+
 def _check_tree(mipt, oracle, nodes, vtx, idx, enc):
     T = idx.shape[0]
     assert nodes.shape[0] == 2 * T - 1

@@ -127,29 +127,31 @@ def lucy(ctx):
 
 
 def gpubuild(ctx):
-    """pt_scene_build (GPU linear BVH) against pt_bvh_build + pt_scene_create (host SAH):
+    """pt_scene_build (GPU: locally-ordered clustering, or the Morton radix tree) against
+    pt_bvh_build + pt_scene_create (host SAH):
     time to a traceable scene from host arrays, and the tracing rate each tree gives."""
     out = {"config": "BVH build: GPU linear BVH vs host SAH", "scenes": []}
     for name, (vtx, idx, mats, mids) in (("atrium 262k", scenes.atrium(262144, seed=42)),
                                          ("clutter 10M", scenes.clutter(10_000_000, seed=11)),
-                                         ("sphere 28M", scenes.displaced_sphere(28_000_000, seed=7))):
+                                         ("sphere 28M", scenes.displaced_sphere(28_000_000, seed=7)))[:int(os.environ.get("GPUBUILD_SCENES", "3"))]:
         n = 1 << 22
         rays = scenes.surface_rays(vtx, idx, n, seed=7)
         d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
         d_h = torch.empty_like(d_r)
         row = {"scene": name, "tris": int(idx.shape[0])}
         hits = {}
-        for kind in ("gpu_lbvh", "host_sah"):
+        for kind in ("gpu_ploc", "gpu_lbvh", "host_sah"):
+            ctx.set_option("build.ploc_radius", 8 if kind == "gpu_ploc" else 0)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            if kind == "gpu_lbvh":
+            if kind != "host_sah":
                 sc = mipt.Scene(ctx, None, vtx, idx, mats, mids, link_encoding=mipt.PT_LINKS_INT_BITS)
             else:
                 nodes, _ = build(vtx, idx, "int")
                 sc = mipt.Scene(ctx, nodes, vtx, idx, mats, mids, link_encoding=mipt.PT_LINKS_INT_BITS)
             ctx.synchronize()
             row[kind + "_scene_s"] = time.perf_counter() - t0
-            if kind == "gpu_lbvh":                     # second build: allocator and code warm
+            if kind != "host_sah":                     # second build: allocator and code warm
                 sc.close()
                 t0 = time.perf_counter()
                 sc = mipt.Scene(ctx, None, vtx, idx, mats, mids, link_encoding=mipt.PT_LINKS_INT_BITS)
@@ -159,11 +161,14 @@ def gpubuild(ctx):
             dt = timed(lambda: sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr()), ctx, 5)
             row[kind + "_mrays_s"] = n / dt / 1e6
             row[kind + "_box_tests_per_ray"] = stc.box_tests / n
+            row[kind + "_tri_tests_per_ray"] = stc.tri_tests / n
+            row[kind + "_re_resolved_rays"] = int(stc.tie_rays)
             hits[kind] = d_h.view(torch.int32)[:, 1].clone(), d_h[:, 7].clone()
             sc.close()
         # both trees must find the same nearest distance (ids can differ between exact ties)
-        row["same_t"] = bool(torch.equal(hits["gpu_lbvh"][1], hits["host_sah"][1]))
-        row["same_primid_fraction"] = float((hits["gpu_lbvh"][0] == hits["host_sah"][0]).float().mean().item())
+        row["same_t"] = bool(torch.equal(hits["gpu_lbvh"][1], hits["host_sah"][1]) and
+                             torch.equal(hits["gpu_ploc"][1], hits["host_sah"][1]))
+        row["same_primid_fraction"] = float((hits["gpu_ploc"][0] == hits["host_sah"][0]).float().mean().item())
         out["scenes"].append(row)
         print(json.dumps(row), flush=True)
     return out
