@@ -680,7 +680,10 @@ int pt_trace_any_device(pt_context *ctx, const pt_scene *scene, const pt_ray *ra
         return fail(PT_ERR_INVALID, "pt_trace_any_device: null argument");
     if (scene->ctx != ctx) return fail(PT_ERR_INVALID, "scene belongs to another context");
     HIP_CHECK(hipSetDevice(ctx->device));
-    launch_trace_any(ctx->stream, scene->dev, rays_dev, occluded_dev, n, ctx->any_exact_order != 0);
+    if (n > 0xFFFFFFF0ull)
+        return fail(PT_ERR_INVALID, "pt_trace_any: more than 2^32-16 rays in one call");
+    launch_trace_any(ctx->stream, scene->dev, rays_dev, occluded_dev, n, ctx->any_exact_order != 0,
+                     ctx->extend_config());
     HIP_CHECK(hipGetLastError());
     return PT_OK;
 }
@@ -691,6 +694,8 @@ int pt_trace_any(pt_context *ctx, const pt_scene *scene, const pt_ray *rays, uin
         return fail(PT_ERR_INVALID, "pt_trace_any: null argument");
     if (scene->ctx != ctx) return fail(PT_ERR_INVALID, "scene belongs to another context");
     if (n == 0) return PT_OK;
+    if (n > 0xFFFFFFF0ull)
+        return fail(PT_ERR_INVALID, "pt_trace_any: more than 2^32-16 rays in one call");
     HIP_CHECK(hipSetDevice(ctx->device));
     int rc = ctx->io_rays.reserve(sizeof(pt_ray) * n);
     if (rc != PT_OK) return rc;
@@ -699,7 +704,7 @@ int pt_trace_any(pt_context *ctx, const pt_scene *scene, const pt_ray *rays, uin
     HIP_CHECK(hipMemcpyAsync(ctx->io_rays.ptr, rays, sizeof(pt_ray) * n, hipMemcpyHostToDevice,
                              ctx->stream));
     launch_trace_any(ctx->stream, scene->dev, (const pt_ray *)ctx->io_rays.ptr,
-                     (int32_t *)ctx->io_hits.ptr, n, ctx->any_exact_order != 0);
+                     (int32_t *)ctx->io_hits.ptr, n, ctx->any_exact_order != 0, ctx->extend_config());
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(occluded, ctx->io_hits.ptr, sizeof(int32_t) * n,
                              hipMemcpyDeviceToHost, ctx->stream));

@@ -70,7 +70,7 @@ unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &
 // Occlusion query.  exact_order: walk the skip links as the reference does; otherwise the
 // two-child nodes, nearer child first (the answer is the same).
 void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, int32_t *occluded,
-                      uint64_t n, bool exact_order);
+                      uint64_t n, bool exact_order, const ExtendConfig &cfg);
 
 void launch_raygen(hipStream_t st, const pt_camera &cam, uint32_t width, uint32_t height,
                    pt_ray *rays);

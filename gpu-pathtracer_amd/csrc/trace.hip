@@ -91,6 +91,20 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(DeviceScene s, const pt_ra
     occluded[i] = occ ? 1 : 0;
 }
 
+// The same query by persistent waves (lane refill, step voting), as the closest-hit kernel.
+struct OccludedSink {
+    int32_t *out;
+    __device__ __forceinline__ void operator()(uint32_t ray, bool occluded) const {
+        out[ray] = occluded ? 1 : 0;
+    }
+};
+__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_persistent(
+    DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, int refill, int leaf_lanes) {
+    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
+    persistent_traverse<false, true>(s, rays, n, true, refill, leaf_lanes, s_stack + threadIdx.x,
+                                     nullptr, nullptr, OccludedSink{occluded});
+}
+
 // Sort key of a ray: 30-bit Morton code of its origin's cell in a 1024^3 grid over the scene's
 // root box.  Rays that start close together walk the same part of the tree; on scenes much
 // larger than the caches that is worth more than the sort costs.
@@ -204,9 +218,17 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
 }
 
 void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, int32_t *occluded,
-                      uint64_t n, bool exact_order) {
+                      uint64_t n, bool exact_order, const ExtendConfig &cfg) {
     if (n == 0) return;
     const bool wide = !exact_order && s.n_tri >= 2;
+    if (wide && cfg.persistent_blocks > 0) {
+        static int occ = 0;
+        const unsigned int grid = (unsigned int)std::min<uint64_t>(
+            grid_for(n), persistent_grid((const void *)k_trace_any_persistent, kBlock, cfg, &occ));
+        hipLaunchKernelGGL(k_trace_any_persistent, dim3(grid), dim3(kBlock), 0, st, s, rays, occluded,
+                           (uint32_t)n, cfg.refill, cfg.leaf_lanes);
+        return;
+    }
     hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays, occluded, n,
                        wide);
 }
