@@ -187,8 +187,15 @@ def main():
                          "kernel": "k_pt_extend_persistent<false>", "launches": int(launches),
                          "avg_launch_ms": extend_ms / max(launches, 1),
                          "kernel_time_share": extend_ms * 1e-3 / elapsed,
-                         "note": "algorithmic reference-layout bytes; the 34 MB scene is cache "
-                                 "resident, so this is not HBM traffic"},
+                         "note": "algorithmic reference-layout bytes; the scene's 46 MB of traversal "
+                                 "data are cache resident, so this is not HBM traffic and the "
+                                 "fraction can exceed 1",
+                         # what the kernel really does: dependent gathers of 64-byte node and
+                         # 48-byte triangle records; beside it the rate of a bare gather kernel
+                         # (tools/micro/gather_nodes.hip, every lane of 5 resident workgroups
+                         # per CU chasing random 64-byte records) measured on this GPU model
+                         "records_per_s": (n_box / 2 + n_tri) * rays / (extend_ms * 1e-3),
+                         "gather_microbenchmark_records_per_s": {"16 MB table": 133e9, "2 MB table": 212e9}},
         }
         # HBM-side bytes per launch of that kernel come from hardware counters, which a
         # benchmark cannot read on itself: they are taken from the committed rocprofv3 --pmc
