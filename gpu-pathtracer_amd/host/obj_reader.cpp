@@ -23,13 +23,8 @@
 
 #include "../../include/mipt.h"
 #include "../csrc/internal.h"
+#include "mesh.h"
 
-struct pt_mesh {
-    std::vector<float> vtx;
-    std::vector<int32_t> idx;
-    std::vector<int32_t> mat_ids;
-    std::vector<pt_material> materials;
-};
 
 namespace {
 

@@ -104,6 +104,7 @@ _PROTOS = {
     "pt_bvh_linearize": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp]),
     "pt_bvh_validate": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "pt_obj_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "pt_gltf_load": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(_vp)]),
     "pt_mesh_vertex_count": (C.c_uint32, [_vp]),
     "pt_mesh_triangle_count": (C.c_uint32, [_vp]),
     "pt_mesh_material_count": (C.c_uint32, [_vp]),
@@ -267,12 +268,18 @@ def validate_bvh(nodes, n_tri=0, link_encoding=PT_LINKS_FLOAT_VALUE) -> None:
     _check(lib.pt_bvh_validate(_ptr(nodes), nodes.shape[0], link_encoding, n_tri))
 
 
-class Mesh:
-    """Result of ``pt_obj_load`` copied into numpy arrays."""
+PT_GLTF_FIRST_MESH_ONLY = 1
 
-    def __init__(self, path: str, normalize: bool = False):
+
+class Mesh:
+    """Result of ``pt_obj_load`` (or ``pt_gltf_load`` for .gltf / .glb) copied into numpy arrays."""
+
+    def __init__(self, path: str, normalize: bool = False, gltf_flags: int = 0):
         h = _vp()
-        _check(lib.pt_obj_load(os.fsencode(path), C.byref(h)))
+        if str(path).lower().endswith((".gltf", ".glb")):
+            _check(lib.pt_gltf_load(os.fsencode(path), gltf_flags, C.byref(h)))
+        else:
+            _check(lib.pt_obj_load(os.fsencode(path), C.byref(h)))
         try:
             if normalize:
                 _check(lib.pt_mesh_normalize_unit_cube(h))

@@ -147,6 +147,13 @@ int pt_bvh_validate(const pt_bbox *nodes, uint32_t n_nodes, uint32_t link_encodi
  * src/main.cpp:860-899 (attrib.vertices, mesh.indices[].vertex_index of every shape,
  * triangulated), plus per-face material ids and the MTL Kd/Ks/Ke/Ns entries. */
 int pt_obj_load(const char *path, pt_mesh **out);
+/* glTF 2.0 (.gltf / .glb), the live application's scene format
+ * (scene_loader_.load_scene, src/main_granite.cpp:265-268).  PT_GLTF_FIRST_MESH_ONLY gives what
+ * that application uses: the first triangle primitive's positions and indices, untransformed
+ * (:286-298).  Without it every triangle primitive of the default scene is merged, positions
+ * in world space, with base colour / metallic / roughness / emissive factors as materials. */
+#define PT_GLTF_FIRST_MESH_ONLY 1u
+int pt_gltf_load(const char *path, uint32_t flags, pt_mesh **out);
 uint32_t pt_mesh_vertex_count(const pt_mesh *m);
 uint32_t pt_mesh_triangle_count(const pt_mesh *m);
 uint32_t pt_mesh_material_count(const pt_mesh *m);

@@ -1,0 +1,129 @@
+"""The glTF 2.0 reader (pt_gltf_load): the live application's scene format
+(src/main_granite.cpp:265-268).  Files are written here, byte by byte, from known arrays."""
+import base64
+import json
+import struct
+
+import numpy as np
+import pytest
+
+
+def _document(tmp_path, kind):
+    """Two meshes: an indexed quad (u16) under a translated, scaled node, and a non-indexed
+    triangle in a child node rotated 90 degrees about z; interleaved positions for the quad."""
+    quad = np.float32([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]])
+    quad_idx = np.uint16([0, 1, 2, 0, 2, 3])
+    tri = np.float32([[1, 0, 0], [2, 0, 0], [1, 0, 1]])
+    inter = np.zeros((4, 5), dtype=np.float32)          # stride 20: xyz + 2 floats of padding
+    inter[:, :3] = quad
+    blob = inter.tobytes() + quad_idx.tobytes() + tri.tobytes()
+    o_idx, o_tri = inter.nbytes, inter.nbytes + quad_idx.nbytes
+    doc = {
+        "asset": {"version": "2.0"},
+        "scene": 0,
+        "scenes": [{"nodes": [0]}],
+        "nodes": [
+            {"mesh": 0, "translation": [10, 0, 0], "scale": [2, 2, 2], "children": [1]},
+            {"mesh": 1, "rotation": [0, 0, 0.7071067811865476, 0.7071067811865476]},
+        ],
+        "meshes": [
+            {"primitives": [{"attributes": {"POSITION": 0}, "indices": 1, "material": 0}]},
+            {"primitives": [{"attributes": {"POSITION": 2}, "material": 1},
+                            {"attributes": {"POSITION": 2}, "mode": 1}]},      # lines: skipped
+        ],
+        "materials": [
+            {"pbrMetallicRoughness": {"baseColorFactor": [0.8, 0.4, 0.2, 1], "metallicFactor": 0.0,
+                                      "roughnessFactor": 0.5}},
+            {"pbrMetallicRoughness": {"baseColorFactor": [1, 1, 1, 1], "metallicFactor": 1.0},
+             "emissiveFactor": [1, 0.5, 0.25],
+             "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 4.0}}},
+        ],
+        "buffers": [{"byteLength": len(blob)}],
+        "bufferViews": [
+            {"buffer": 0, "byteOffset": 0, "byteLength": inter.nbytes, "byteStride": 20},
+            {"buffer": 0, "byteOffset": o_idx, "byteLength": quad_idx.nbytes},
+            {"buffer": 0, "byteOffset": o_tri, "byteLength": tri.nbytes},
+        ],
+        "accessors": [
+            {"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"},
+            {"bufferView": 1, "componentType": 5123, "count": 6, "type": "SCALAR"},
+            {"bufferView": 2, "componentType": 5126, "count": 3, "type": "VEC3"},
+        ],
+    }
+    if kind == "glb":
+        js = json.dumps(doc).encode()
+        js += b" " * (-len(js) % 4)
+        bn = blob + b"\0" * (-len(blob) % 4)
+        body = struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(bn), 0x004E4942) + bn
+        path = tmp_path / "scene.glb"
+        path.write_bytes(struct.pack("<III", 0x46546C67, 2, 12 + len(body)) + body)
+    elif kind == "external":
+        (tmp_path / "scene.bin").write_bytes(blob)
+        doc["buffers"][0]["uri"] = "scene.bin"
+        path = tmp_path / "scene.gltf"
+        path.write_text(json.dumps(doc, indent=1))
+    else:
+        doc["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(blob).decode()
+        path = tmp_path / "scene.gltf"
+        path.write_text(json.dumps(doc))
+    return str(path), quad, quad_idx, tri
+
+
+@pytest.mark.parametrize("kind", ["glb", "external", "base64"])
+def test_gltf_scene_is_flattened_to_world_space(mipt, tmp_path, kind):
+    path, quad, quad_idx, tri = _document(tmp_path, kind)
+    m = mipt.Mesh(path)
+    assert m.vtx.shape == (7, 3) and m.idx.shape == (3, 3)
+    np.testing.assert_allclose(m.vtx[:4], quad * 2 + [10, 0, 0], rtol=0, atol=1e-6)
+    # child: parent (translate, scale 2) x rotation by 90 degrees about z: (x, y, z) -> (-y, x, z)
+    rot = np.stack([-tri[:, 1], tri[:, 0], tri[:, 2]], axis=1)
+    np.testing.assert_allclose(m.vtx[4:], rot * 2 + [10, 0, 0], rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(m.idx, [[0, 1, 2], [0, 2, 3], [4, 5, 6]])
+    np.testing.assert_array_equal(m.material_ids, [0, 0, 1])
+    a, b = m.materials[0], m.materials[1]
+    np.testing.assert_allclose(a["kd"], [0.8, 0.4, 0.2])
+    np.testing.assert_allclose(a["ks"], [0.04] * 3)
+    assert a["roughness"] == pytest.approx(0.5) and not a["ke"].any()
+    np.testing.assert_allclose(b["kd"], [0, 0, 0])
+    np.testing.assert_allclose(b["ks"], [1, 1, 1])
+    np.testing.assert_allclose(b["ke"], [4, 2, 1])
+
+
+def test_gltf_first_mesh_only_is_what_the_reference_uses(mipt, tmp_path):
+    """src/main_granite.cpp:286-298: the first mesh, positions as stored."""
+    path, quad, quad_idx, _ = _document(tmp_path, "glb")
+    m = mipt.Mesh(path, gltf_flags=mipt.PT_GLTF_FIRST_MESH_ONLY)
+    np.testing.assert_array_equal(m.vtx, quad)
+    np.testing.assert_array_equal(m.idx.reshape(-1), quad_idx.astype(np.int32))
+    # and it goes through the BVH path like any mesh
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(m.vtx, m.idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+    mipt.validate_bvh(nodes, 2)
+
+
+def test_gltf_errors(mipt, tmp_path):
+    with pytest.raises(mipt.MiptError, match="cannot open"):
+        mipt.Mesh(str(tmp_path / "nope.glb"))
+    p = tmp_path / "bad.gltf"
+    p.write_text("{\"asset\": {\"version\": \"2.0\"}, \"meshes\": [")
+    with pytest.raises(mipt.MiptError, match="JSON"):
+        mipt.Mesh(str(p))
+    p.write_text(json.dumps({"asset": {"version": "2.0"}, "scenes": [{"nodes": []}]}))
+    with pytest.raises(mipt.MiptError, match="no triangles"):
+        mipt.Mesh(str(p))
+    path, *_ = _document(tmp_path, "external")
+    doc = json.loads(open(path).read())
+    doc["accessors"][1]["count"] = 600                      # indices beyond the buffer
+    open(path, "w").write(json.dumps(doc))
+    with pytest.raises(mipt.MiptError, match="beyond its buffer"):
+        mipt.Mesh(path)
+    doc["accessors"][1]["count"] = 6
+    doc["accessors"][0]["count"] = 2                        # index 2, 3 outside the vertices
+    open(path, "w").write(json.dumps(doc))
+    with pytest.raises(mipt.MiptError, match="outside the primitive"):
+        mipt.Mesh(path)
+    raw = open(str(tmp_path / "scene.bin"), "rb").read()
+    open(str(tmp_path / "scene.bin"), "wb").write(raw[:10])
+    doc["accessors"][0]["count"] = 4
+    open(path, "w").write(json.dumps(doc))
+    with pytest.raises(mipt.MiptError, match="shorter than"):
+        mipt.Mesh(path)
