@@ -1,8 +1,9 @@
 // ptrender: a host program of the shape of the reference's application, written against the
-// C ABI only (include/mipt.h): load an OBJ (src/main.cpp:852-899), build the BVH and upload
+// C ABI only (include/mipt.h): load an OBJ (src/main.cpp:852-899) or glTF
+// (src/main_granite.cpp:265-268) scene, build the BVH and upload
 // the scene (src/main_granite.cpp:115-194), render, write an image.
 //
-//   ptrender scene.obj out.ppm [--size W H] [--spp N] [--depth D] [--nee] [--gpu-build]
+//   ptrender scene.obj|scene.gltf|scene.glb out.ppm [--size W H] [--spp N] [--depth D] [--nee] [--gpu-build]
 //            [--eye x y z] [--target x y z] [--fov deg] [--seed S] [--film out.raw]
 //
 // --film writes the raw film (W*H float4: rgb sums and sample count) for exact comparisons.
@@ -59,7 +60,13 @@ int main(int argc, char **argv) {
     }
 
     pt_mesh *mesh = nullptr;
-    CHECK(pt_obj_load(argv[1], &mesh));
+    const std::string scene_path = argv[1];
+    auto ends_with = [&](const char *suffix) {
+        const size_t n = std::strlen(suffix);
+        return scene_path.size() >= n && scene_path.compare(scene_path.size() - n, n, suffix) == 0;
+    };
+    if (ends_with(".glb") || ends_with(".gltf")) CHECK(pt_gltf_load(argv[1], 0, &mesh));   // src/main_granite.cpp:268
+    else CHECK(pt_obj_load(argv[1], &mesh));
     const uint32_t n_vtx = pt_mesh_vertex_count(mesh), n_tri = pt_mesh_triangle_count(mesh);
     std::printf("%s: %u vertices, %u triangles, %u materials\n", argv[1], n_vtx, n_tri,
                 pt_mesh_material_count(mesh));
