@@ -7,6 +7,7 @@
 // write) is what the BVH cache offers the caller.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -158,8 +159,14 @@ int pt_film_load(pt_film *film, const char *path) {
 
 int pt_film_write_image(pt_film *film, const char *path, uint32_t format, float exposure) {
     if (!film || !path) return fail(PT_ERR_INVALID, "pt_film_write_image: null argument");
-    if (format != PT_IMAGE_PPM && format != PT_IMAGE_PFM)
+    const uint32_t container = format & 0xffu, curve = format & ~0xffu;
+    if (container != PT_IMAGE_PPM && container != PT_IMAGE_PFM && container != PT_IMAGE_PNG)
         return fail(PT_ERR_INVALID, "pt_film_write_image: unknown format");
+    if (curve != 0 && curve != PT_IMAGE_TONEMAP_REINHARD && curve != PT_IMAGE_TONEMAP_FILMIC)
+        return fail(PT_ERR_INVALID, "pt_film_write_image: unknown tone curve");
+    if (curve != 0 && container == PT_IMAGE_PFM)
+        return fail(PT_ERR_INVALID, "pt_film_write_image: PFM holds linear radiance; a tone curve "
+                                    "applies to the 8-bit formats only");
     if (!(exposure > 0.f)) return fail(PT_ERR_INVALID, "pt_film_write_image: exposure must be > 0");
     const uint32_t W = film->width, H = film->height;
     std::vector<float> px;
@@ -176,8 +183,34 @@ int pt_film_write_image(pt_film *film, const char *path, uint32_t format, float 
         const float *p = px.data() + 4 * ((size_t)y * W + x);
         return p[3] > 0.f ? p[c] / p[3] * exposure : 0.f;
     };
+    // Display value of one pixel: tone curve on the luminance-preserving RGB triple, clamp,
+    // sRGB transfer function, 8 bits.
+    auto encode_pixel = [&](uint32_t x, uint32_t y, unsigned char *out) {
+        float v[3];
+        for (int c = 0; c < 3; ++c) {
+            v[c] = mean(x, y, c);
+            if (!(v[c] >= 0.f)) v[c] = 0.f;       // NaN and negative radiance show as black
+        }
+        if (curve == PT_IMAGE_TONEMAP_REINHARD) {
+            // Reinhard on luminance: L -> L / (1 + L), colour ratios kept.
+            const float L = 0.2126f * v[0] + 0.7152f * v[1] + 0.0722f * v[2];
+            const float s = 1.f / (1.f + L);
+            for (int c = 0; c < 3; ++c) v[c] *= s;
+        } else if (curve == PT_IMAGE_TONEMAP_FILMIC) {
+            // Per-channel rational fit of the ACES reference rendering curve (Narkowicz 2015).
+            for (int c = 0; c < 3; ++c) {
+                const float t = v[c];
+                v[c] = (t * (2.51f * t + 0.03f)) / (t * (2.43f * t + 0.59f) + 0.14f);
+            }
+        }
+        for (int c = 0; c < 3; ++c) {
+            float t = std::fmin(v[c], 1.f);
+            t = t <= 0.0031308f ? 12.92f * t : 1.055f * std::pow(t, 1.f / 2.4f) - 0.055f;
+            out[c] = (unsigned char)std::lround(t * 255.f);
+        }
+    };
     bool ok = true;
-    if (format == PT_IMAGE_PFM) {                 // linear floats, bottom row first
+    if (container == PT_IMAGE_PFM) {              // linear floats, bottom row first
         ok = std::fprintf(f.get(), "PF\n%u %u\n-1.0\n", W, H) > 0;
         std::vector<float> row(3 * (size_t)W);
         for (uint32_t y = H; ok && y-- > 0;) {
@@ -185,19 +218,88 @@ int pt_film_write_image(pt_film *film, const char *path, uint32_t format, float 
                 for (int c = 0; c < 3; ++c) row[3 * (size_t)x + c] = mean(x, y, c);
             ok = std::fwrite(row.data(), sizeof(float), row.size(), f.get()) == row.size();
         }
-    } else {                                      // 8-bit, sRGB transfer curve
+    } else if (container == PT_IMAGE_PPM) {
         ok = std::fprintf(f.get(), "P6\n%u %u\n255\n", W, H) > 0;
         std::vector<unsigned char> row(3 * (size_t)W);
         for (uint32_t y = 0; ok && y < H; ++y) {
-            for (uint32_t x = 0; x < W; ++x)
-                for (int c = 0; c < 3; ++c) {
-                    float v = mean(x, y, c);
-                    v = v != v ? 0.f : std::fmin(std::fmax(v, 0.f), 1.f);
-                    v = v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1.f / 2.4f) - 0.055f;
-                    row[3 * (size_t)x + c] = (unsigned char)std::lround(v * 255.f);
-                }
+            for (uint32_t x = 0; x < W; ++x) encode_pixel(x, y, &row[3 * (size_t)x]);
             ok = std::fwrite(row.data(), 1, row.size(), f.get()) == row.size();
         }
+    } else {
+        // PNG, 8-bit RGB, no interlace.  The image data is a zlib stream of "stored" deflate
+        // blocks (no compression: nothing to link against, and a decoder reads it like any
+        // other PNG); every scanline starts with filter byte 0.
+        std::vector<unsigned char> raw;
+        try {
+            raw.resize((size_t)H * (1 + 3 * (size_t)W));
+        } catch (const std::bad_alloc &) {
+            return fail(PT_ERR_NOMEM, "out of host memory");
+        }
+        for (uint32_t y = 0; y < H; ++y) {
+            unsigned char *row = &raw[(size_t)y * (1 + 3 * (size_t)W)];
+            row[0] = 0;
+            for (uint32_t x = 0; x < W; ++x) encode_pixel(x, y, row + 1 + 3 * (size_t)x);
+        }
+        uint32_t crc_table[256];
+        for (uint32_t n = 0; n < 256; ++n) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_table[n] = c;
+        }
+        auto crc_update = [&](uint32_t c, const unsigned char *d, size_t n) {
+            for (size_t i = 0; i < n; ++i) c = crc_table[(c ^ d[i]) & 0xffu] ^ (c >> 8);
+            return c;
+        };
+        auto be32 = [](unsigned char *o, uint32_t v) {
+            o[0] = (unsigned char)(v >> 24); o[1] = (unsigned char)(v >> 16);
+            o[2] = (unsigned char)(v >> 8);  o[3] = (unsigned char)v;
+        };
+        auto chunk = [&](const char type[4], const unsigned char *d, size_t n) {
+            unsigned char hdr[8], tail[4];
+            be32(hdr, (uint32_t)n);
+            std::memcpy(hdr + 4, type, 4);
+            uint32_t c = crc_update(0xffffffffu, hdr + 4, 4);
+            c = crc_update(c, d, n) ^ 0xffffffffu;
+            be32(tail, c);
+            return std::fwrite(hdr, 1, 8, f.get()) == 8 &&
+                   (n == 0 || std::fwrite(d, 1, n, f.get()) == n) &&
+                   std::fwrite(tail, 1, 4, f.get()) == 4;
+        };
+        static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+        unsigned char ihdr[13];
+        be32(ihdr, W);
+        be32(ihdr + 4, H);
+        ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+        ok = std::fwrite(sig, 1, 8, f.get()) == 8 && chunk("IHDR", ihdr, 13);
+
+        const size_t kBlock = 65535, n_blocks = (raw.size() + kBlock - 1) / kBlock;
+        std::vector<unsigned char> z;
+        if (2 + raw.size() + 5 * n_blocks + 4 > 0x7fffffffull)
+            return fail(PT_ERR_INVALID, "pt_film_write_image: image too large for one PNG data chunk");
+        try {
+            z.reserve(2 + raw.size() + 5 * n_blocks + 4);
+        } catch (const std::bad_alloc &) {
+            return fail(PT_ERR_NOMEM, "out of host memory");
+        }
+        z.push_back(0x78); z.push_back(0x01);
+        uint32_t s1 = 1, s2 = 0;                  // Adler-32 of the uncompressed bytes
+        for (size_t off = 0, blk = 0; blk < n_blocks; ++blk, off += kBlock) {
+            const size_t len = std::min(kBlock, raw.size() - off);
+            z.push_back(blk + 1 == n_blocks ? 1 : 0);
+            z.push_back((unsigned char)(len & 0xff)); z.push_back((unsigned char)(len >> 8));
+            z.push_back((unsigned char)(~len & 0xff)); z.push_back((unsigned char)((~len >> 8) & 0xff));
+            z.insert(z.end(), raw.begin() + (ptrdiff_t)off, raw.begin() + (ptrdiff_t)(off + len));
+            for (size_t i = 0; i < len;) {        // 5552 bytes keep both sums below 2^32
+                const size_t run = std::min<size_t>(5552, len - i);
+                for (size_t k = 0; k < run; ++k) { s1 += raw[off + i + k]; s2 += s1; }
+                s1 %= 65521u; s2 %= 65521u;
+                i += run;
+            }
+        }
+        unsigned char adler[4];
+        be32(adler, (s2 << 16) | s1);
+        z.insert(z.end(), adler, adler + 4);
+        ok = ok && chunk("IDAT", z.data(), z.size()) && chunk("IEND", nullptr, 0);
     }
     if (!ok) return fail(PT_ERR_IO, std::string("pt_film_write_image: short write to ") + path);
     return PT_OK;

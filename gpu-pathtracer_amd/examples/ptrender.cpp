@@ -3,7 +3,7 @@
 // (src/main_granite.cpp:265-268) scene, build the BVH and upload
 // the scene (src/main_granite.cpp:115-194), render, write an image.
 //
-//   ptrender scene.obj|scene.gltf|scene.glb out.ppm [--size W H] [--spp N] [--depth D] [--nee] [--gpu-build]
+//   ptrender scene.obj|scene.gltf|scene.glb out.ppm|.png|.pfm [--size W H] [--spp N] [--depth D] [--nee] [--gpu-build]
 //            [--eye x y z] [--target x y z] [--fov deg] [--seed S] [--film out.raw]
 //
 // --film writes the raw film (W*H float4: rgb sums and sample count) for exact comparisons.
@@ -34,7 +34,7 @@ static void cross(const double a[3], const double b[3], double out[3]) {
 
 int main(int argc, char **argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: ptrender scene.obj out.ppm [--size W H] [--spp N] [--depth D] "
+        std::fprintf(stderr, "usage: ptrender scene.obj out.ppm|.png|.pfm [--size W H] [--spp N] [--depth D] "
                              "[--nee] [--gpu-build] [--eye x y z] [--target x y z] [--fov deg] "
                              "[--seed S] [--film out.raw]\n");
         return 2;
@@ -127,7 +127,14 @@ int main(int argc, char **argv) {
     std::printf("%llu paths, %llu primary + %llu bounce + %llu shadow rays\n",
                 (unsigned long long)st.paths, (unsigned long long)st.rays_primary,
                 (unsigned long long)st.rays_bounce, (unsigned long long)st.rays_shadow);
-    CHECK(pt_film_write_image(film, argv[2], PT_IMAGE_PPM, 1.0f));
+    // container by file extension: .png, .pfm, anything else is PPM
+    const std::string out_path = argv[2];
+    auto out_ends_with = [&](const char *ext) {
+        const size_t n = std::strlen(ext);
+        return out_path.size() >= n && out_path.compare(out_path.size() - n, n, ext) == 0;
+    };
+    const uint32_t fmt = out_ends_with(".png") ? PT_IMAGE_PNG : out_ends_with(".pfm") ? PT_IMAGE_PFM : PT_IMAGE_PPM;
+    CHECK(pt_film_write_image(film, argv[2], fmt, 1.0f));
     if (film_path) {
         std::vector<float> px(4ull * W * H);
         CHECK(pt_film_read(film, px.data()));

@@ -26,7 +26,8 @@ lib = C.CDLL(LIB_PATH)
 
 # ---------------------------------------------------------------- constants
 PT_OK, PT_ERR_INVALID, PT_ERR_DEVICE, PT_ERR_UNSUPPORTED, PT_ERR_IO, PT_ERR_NOMEM, PT_ERR_STALE = range(7)
-PT_IMAGE_PPM, PT_IMAGE_PFM = 0, 1
+PT_IMAGE_PPM, PT_IMAGE_PFM, PT_IMAGE_PNG = 0, 1, 2
+PT_IMAGE_TONEMAP_REINHARD, PT_IMAGE_TONEMAP_FILMIC = 0x100, 0x200
 PT_LINKS_FLOAT_VALUE, PT_LINKS_INT_BITS = 0, 1
 PT_CAMERA_REFERENCE, PT_CAMERA_PINHOLE = 0, 1
 PT_TRACE_DEFAULT, PT_TRACE_EXACT_ORDER, PT_TRACE_MOLLER_TRUMBORE, PT_TRACE_NO_TIE_FIXUP = 0, 1, 2, 4

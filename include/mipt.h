@@ -280,6 +280,11 @@ int pt_film_save(pt_film *film, const char *path);
 int pt_film_load(pt_film *film, const char *path);
 #define PT_IMAGE_PPM 0u   /* 8-bit binary PPM, sRGB transfer curve, clamped */
 #define PT_IMAGE_PFM 1u   /* 32-bit float PFM, linear */
+#define PT_IMAGE_PNG 2u   /* 8-bit RGB PNG (uncompressed data stream), sRGB transfer curve */
+/* Tone curve for the 8-bit formats, OR-ed into format; without one values are clamped at 1.
+ * (Image output is on the reference's to-do list only, src/main_granite.cpp:285,389.) */
+#define PT_IMAGE_TONEMAP_REINHARD 0x100u   /* L / (1 + L) on luminance */
+#define PT_IMAGE_TONEMAP_FILMIC   0x200u   /* per-channel rational fit of the ACES curve */
 /* Writes rgb / sample count, scaled by exposure. */
 int pt_film_write_image(pt_film *film, const char *path, uint32_t format, float exposure);
 

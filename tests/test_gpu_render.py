@@ -222,6 +222,40 @@ def test_film_checkpoint_resume_and_image(mipt, scenes, gpu_ctx, tmp_path):
         lin = np.frombuffer(rawf[len(head):], dtype=np.float32).reshape(H, W, 3)[::-1]
         f = full.read()
         np.testing.assert_allclose(lin, f[..., :3] / f[..., 3:] * 2.0, rtol=1e-6)
+        # PNG: same pixels as the PPM, in a stream any decoder accepts (zlib checks the Adler-32,
+        # the chunk CRCs are checked here)
+        import struct
+        import zlib
+        png = str(tmp_path / "o.png")
+        full.write_image(png, mipt.PT_IMAGE_PNG)
+        rawp = open(png, "rb").read()
+        assert rawp[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, chunks = 8, []
+        while pos < len(rawp):
+            n, typ = struct.unpack(">I4s", rawp[pos:pos + 8])
+            body = rawp[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", rawp[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+            chunks.append((typ, body))
+            pos += 12 + n
+        assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+        assert struct.unpack(">IIBBBBB", chunks[0][1]) == (W, H, 8, 2, 0, 0, 0)
+        rows = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(H, 1 + 3 * W)
+        assert not rows[:, 0].any()
+        np.testing.assert_array_equal(rows[:, 1:].reshape(H, W, 3), img)
+        # tone curves: monotone, below the clamped image where that one saturates
+        for curve in (mipt.PT_IMAGE_TONEMAP_REINHARD, mipt.PT_IMAGE_TONEMAP_FILMIC):
+            full.write_image(ppm, mipt.PT_IMAGE_PPM | curve, exposure=4.0)
+            tm = np.frombuffer(open(ppm, "rb").read()[13:], dtype=np.uint8).reshape(H, W, 3)
+            full.write_image(ppm, mipt.PT_IMAGE_PPM, exposure=4.0)
+            cl = np.frombuffer(open(ppm, "rb").read()[13:], dtype=np.uint8).reshape(H, W, 3)
+            assert (cl == 255).mean() > (tm == 255).mean()
+            lum = f[..., :3].sum(-1)
+            order = np.argsort(lum.ravel())
+            g = tm[..., 1].ravel()[order].astype(int)
+            grey = np.abs(f[..., 0] - f[..., 1]).ravel()[order] < 1e-6 * lum.ravel()[order]
+            assert (np.diff(g[grey]) >= 0).all()
+        with pytest.raises(mipt.MiptError, match="linear"):
+            full.write_image(pfm, mipt.PT_IMAGE_PFM | mipt.PT_IMAGE_TONEMAP_FILMIC)
         for x in (full, a, b):
             x.close()
     finally:
