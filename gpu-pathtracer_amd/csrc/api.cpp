@@ -571,6 +571,9 @@ uint32_t pt_scene_link_encoding(const pt_scene *scene) { return scene ? scene->d
 
 int pt_scene_read_nodes(pt_scene *scene, pt_bbox *nodes) {
     if (!scene || !nodes) return fail(PT_ERR_INVALID, "pt_scene_read_nodes: null argument");
+    if (scene->dev.tlas)
+        return fail(PT_ERR_UNSUPPORTED, "pt_scene_read_nodes: a two-level scene holds the trees its "
+                                        "creator passed in; there is no single array to read");
     HIP_CHECK(hipSetDevice(scene->ctx->device));
     HIP_CHECK(hipMemcpyAsync(nodes, scene->dev.nodes, sizeof(pt_bbox) * (size_t)scene->dev.n_nodes,
                              hipMemcpyDeviceToHost, scene->ctx->stream));
@@ -600,7 +603,13 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
     const bool mt = (flags & PT_TRACE_MOLLER_TRUMBORE) != 0;
     const bool fixup = (flags & PT_TRACE_NO_TIE_FIXUP) == 0;
     HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(DeviceTraceCounters), st));
-    if (exact) {
+    if (scene->dev.tlas) {
+        if (mt)
+            return fail(PT_ERR_UNSUPPORTED,
+                        "pt_trace_closest: PT_TRACE_MOLLER_TRUMBORE is not available on two-level scenes");
+        launch_trace_two_level(st, scene->dev, rays_dev, hits_dev, n, fixup, exact, ctx->counters,
+                               count);
+    } else if (exact) {
         launch_trace_skiplink(st, scene->dev, rays_dev, hits_dev, n, mt,
                               count ? ctx->counters : nullptr);
     } else {

@@ -1,0 +1,263 @@
+// C ABI: two-level scenes (meshes placed by affine transforms under a top-level BVH).
+//
+// The reference documents the format (src/bvh/bvh_builder.h:29-33: a top-level BVH whose leaf
+// payload is an instance index) but never builds one: its two-level translator is disabled
+// (src/bvh/RadeonRays/plain_bvh_translator.cpp:98-101,134-137) and the application draws one
+// mesh (src/main_granite.cpp:284-298).  The caller builds every tree with pt_bvh_build, the
+// same way the reference builds its single one: one per mesh over the triangle boxes, one over
+// the instances' world boxes (pt_instance_bounds).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mipt.h"
+#include "../host/bvh.h"
+#include "internal.h"
+
+using namespace mipt;
+
+namespace {
+
+int check_meshes(const pt_mesh_desc *meshes, uint32_t n_meshes, const pt_instance *inst,
+                 uint32_t n_inst, const char *who) {
+    if (!meshes || !inst) return fail(PT_ERR_INVALID, std::string(who) + ": null argument");
+    if (n_meshes == 0 || n_inst == 0)
+        return fail(PT_ERR_INVALID, std::string(who) + ": no meshes or no instances");
+    for (uint32_t m = 0; m < n_meshes; ++m) {
+        const pt_mesh_desc &d = meshes[m];
+        if (!d.nodes || !d.vertices || !d.indices || d.n_nodes == 0 || d.n_vertices == 0 ||
+            d.n_triangles == 0)
+            return fail(PT_ERR_INVALID, std::string(who) + ": mesh " + std::to_string(m) +
+                                            " is empty or has a null array");
+    }
+    for (uint32_t i = 0; i < n_inst; ++i) {
+        if (inst[i].mesh >= n_meshes)
+            return fail(PT_ERR_INVALID, std::string(who) + ": instance " + std::to_string(i) +
+                                            " names mesh " + std::to_string(inst[i].mesh));
+        for (int k = 0; k < 12; ++k)
+            if (!std::isfinite(inst[i].object_to_world[k]))
+                return fail(PT_ERR_INVALID, std::string(who) + ": instance " + std::to_string(i) +
+                                                " has a non-finite transform");
+    }
+    return PT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pt_instance_bounds(const pt_mesh_desc *meshes, uint32_t n_meshes, const pt_instance *instances,
+                       uint32_t n_instances, pt_bbox *out) {
+    if (!out) return fail(PT_ERR_INVALID, "pt_instance_bounds: null argument");
+    const int rc = check_meshes(meshes, n_meshes, instances, n_instances, "pt_instance_bounds");
+    if (rc != PT_OK) return rc;
+    for (uint32_t i = 0; i < n_instances; ++i)
+        instance_world_box(instances[i].object_to_world, meshes[instances[i].mesh].nodes[0], out[i]);
+    return PT_OK;
+}
+
+int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint32_t n_meshes,
+                              const pt_instance *instances, uint32_t n_instances,
+                              const pt_bbox *top_nodes, uint32_t n_top_nodes,
+                              uint32_t link_encoding, const pt_material *materials,
+                              uint32_t n_materials, pt_scene **out) {
+    if (!ctx || !top_nodes || !out)
+        return fail(PT_ERR_INVALID, "pt_scene_create_instanced: null argument");
+    *out = nullptr;
+    int rc = check_meshes(meshes, n_meshes, instances, n_instances, "pt_scene_create_instanced");
+    if (rc != PT_OK) return rc;
+    if (materials && n_materials == 0)
+        return fail(PT_ERR_INVALID, "pt_scene_create_instanced: materials given but n_materials is 0");
+    try {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+
+        // Top level: a skip-link tree whose leaves name every instance.
+        BvhTree top;
+        tree_from_skip_links(top_nodes, n_top_nodes, link_encoding, n_instances, top);
+        {
+            std::vector<uint8_t> seen(n_instances, 0);
+            for (size_t i = 0; i < top.size(); ++i)
+                if (top.prim[i] >= 0) seen[(size_t)top.prim[i]] = 1;
+            for (uint32_t k = 0; k < n_instances; ++k)
+                if (!seen[k])
+                    return fail(PT_ERR_INVALID, "pt_scene_create_instanced: instance " +
+                                                    std::to_string(k) + " is in no top-level leaf");
+        }
+
+        std::vector<pt_material> mats;
+        if (materials) {
+            mats.assign(materials, materials + n_materials);
+        } else {
+            pt_material m{};
+            m.kd[0] = m.kd[1] = m.kd[2] = 0.5f;
+            m.roughness = 1.f;
+            mats.push_back(m);
+        }
+
+        // Meshes, back to back, each validated and re-laid-out like a scene of its own.
+        struct MeshOffsets { uint32_t node, wnode, wtri, vtx, tri; };
+        std::vector<MeshOffsets> off(n_meshes);
+        std::vector<pt_bbox> nodes_all;
+        std::vector<float> vtx_all;
+        std::vector<int32_t> idx_all;
+        std::vector<WideNode> wnodes_all;
+        std::vector<TriRecord> wtris_all;
+        uint32_t wide_depth = 0;
+        for (uint32_t m = 0; m < n_meshes; ++m) {
+            const pt_mesh_desc &d = meshes[m];
+            const std::string tag = "pt_scene_create_instanced: mesh " + std::to_string(m) + ": ";
+            BvhTree tree;
+            try {
+                tree_from_skip_links(d.nodes, d.n_nodes, link_encoding, d.n_triangles, tree);
+            } catch (const std::runtime_error &err) {
+                return fail(PT_ERR_INVALID, tag + err.what());
+            }
+            std::vector<uint8_t> seen(d.n_triangles, 0);
+            for (size_t i = 0; i < tree.size(); ++i)
+                if (tree.prim[i] >= 0) seen[(size_t)tree.prim[i]] = 1;
+            for (uint32_t k = 0; k < d.n_triangles; ++k)
+                if (!seen[k]) return fail(PT_ERR_INVALID, tag + "triangle " + std::to_string(k) + " is in no leaf");
+            for (uint64_t i = 0; i < 3ull * d.n_triangles; ++i)
+                if (d.indices[i] < 0 || (uint32_t)d.indices[i] >= d.n_vertices)
+                    return fail(PT_ERR_INVALID, tag + "index " + std::to_string(d.indices[i]) +
+                                                    " outside the vertex buffer");
+            WideBvh wide;
+            build_wide_layout(tree, d.vertices, d.n_vertices, d.indices, d.n_triangles, wide);
+            if (wide.nodes.size() > (1u << 26) || wide.tris.size() > 89000000u)
+                return fail(PT_ERR_UNSUPPORTED, tag + "too large for 32-bit record offsets");
+            if (nodes_all.size() + d.n_nodes > 0x7fffffffull ||
+                vtx_all.size() / 3 + d.n_vertices > 0x7fffffffull ||
+                wtris_all.size() + wide.tris.size() > 0x7fffffffull)
+                return fail(PT_ERR_UNSUPPORTED, "pt_scene_create_instanced: meshes too large together");
+            off[m] = {(uint32_t)nodes_all.size(), (uint32_t)wnodes_all.size(),
+                      (uint32_t)wtris_all.size(), (uint32_t)(vtx_all.size() / 3),
+                      (uint32_t)(idx_all.size() / 3)};
+            nodes_all.insert(nodes_all.end(), d.nodes, d.nodes + d.n_nodes);
+            vtx_all.insert(vtx_all.end(), d.vertices, d.vertices + 3 * (size_t)d.n_vertices);
+            idx_all.insert(idx_all.end(), d.indices, d.indices + 3 * (size_t)d.n_triangles);
+            wnodes_all.insert(wnodes_all.end(), wide.nodes.begin(), wide.nodes.end());
+            wtris_all.insert(wtris_all.end(), wide.tris.begin(), wide.tris.end());
+            if (wide.max_depth > wide_depth) wide_depth = wide.max_depth;
+        }
+
+        // Instances, and one world-space shading record per instanced triangle.
+        uint64_t total_tris = 0;
+        for (uint32_t i = 0; i < n_instances; ++i) total_tris += meshes[instances[i].mesh].n_triangles;
+        if (total_tris > 0x7fffffffull)
+            return fail(PT_ERR_UNSUPPORTED, "pt_scene_create_instanced: more than 2^31 instanced triangles");
+        std::vector<DeviceInstance> dinst(n_instances);
+        std::vector<TriRecord> stris((size_t)total_tris);
+        std::vector<int32_t> mids((size_t)total_tris);
+        std::vector<float> flat_vtx(9 * (size_t)total_tris);   // for the light list only
+        std::vector<int32_t> flat_idx(3 * (size_t)total_tris);
+        uint32_t first = 0;
+        for (uint32_t i = 0; i < n_instances; ++i) {
+            const pt_instance &in = instances[i];
+            const pt_mesh_desc &d = meshes[in.mesh];
+            DeviceInstance &di = dinst[i];
+            if (!invert_affine(in.object_to_world, di.inv))
+                return fail(PT_ERR_INVALID, "pt_scene_create_instanced: the transform of instance " +
+                                                std::to_string(i) + " is not invertible");
+            di.node_off = off[in.mesh].node;
+            di.wnode_off = off[in.mesh].wnode;
+            di.wtri_off = off[in.mesh].wtri;
+            di.vtx_off = off[in.mesh].vtx;
+            di.tri_off = off[in.mesh].tri;
+            di.n_tri = d.n_triangles;
+            di.first_tri = first;
+            di._pad = 0;
+            for (uint32_t t = 0; t < d.n_triangles; ++t) {
+                const int64_t mid = (int64_t)(d.material_ids ? d.material_ids[t] : 0) + in.material_offset;
+                if (mid < 0 || mid >= (int64_t)mats.size())
+                    return fail(PT_ERR_INVALID, "pt_scene_create_instanced: instance " +
+                                                    std::to_string(i) + ", triangle " + std::to_string(t) +
+                                                    ": material " + std::to_string(mid) + " out of range");
+                float w[3][3];
+                for (int j = 0; j < 3; ++j)
+                    transform_point(in.object_to_world,
+                                    d.vertices + 3 * (size_t)d.indices[3 * (size_t)t + j], w[j]);
+                const size_t g = (size_t)first + t;
+                TriRecord &r = stris[g];
+                r.v0[0] = w[0][0]; r.v0[1] = w[0][1]; r.v0[2] = w[0][2];
+                r.v1x = w[1][0]; r.v1yz[0] = w[1][1]; r.v1yz[1] = w[1][2];
+                r.v2xy[0] = w[2][0]; r.v2xy[1] = w[2][1]; r.v2z = w[2][2];
+                r.primid = (int32_t)mid;                  // the shading copy carries the material id
+                r.pad[0] = r.pad[1] = 0;
+                mids[g] = (int32_t)mid;
+                for (int j = 0; j < 3; ++j) {
+                    std::memcpy(&flat_vtx[9 * g + 3 * (size_t)j], w[j], 12);
+                    flat_idx[3 * g + (size_t)j] = (int32_t)(3 * g + (size_t)j);
+                }
+            }
+            first += d.n_triangles;
+        }
+        std::vector<int32_t> light_tri;
+        std::vector<float> light_cdf;
+        build_light_list(flat_vtx.data(), flat_idx.data(), (uint32_t)total_tris, mats.data(),
+                         mids.data(), light_tri, light_cdf);
+        flat_vtx = std::vector<float>();
+        flat_idx = std::vector<int32_t>();
+
+        auto sc = std::make_unique<pt_scene>();
+        sc->ctx = ctx;
+        auto upload = [&](const void *src, size_t bytes) -> void * {
+            void *dst = nullptr;
+            hipError_t err = hipMalloc(&dst, bytes);
+            if (err == hipSuccess) {
+                sc->allocs.push_back(dst);
+                err = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+            }
+            if (err != hipSuccess) {
+                sc->release();
+                throw std::runtime_error(std::string("pt_scene_create_instanced upload: ") +
+                                         hipGetErrorString(err));
+            }
+            return dst;
+        };
+        DeviceScene &d = sc->dev;
+        d.nodes = (const float4 *)upload(nodes_all.data(), sizeof(pt_bbox) * nodes_all.size());
+        d.vtx = (const float *)upload(vtx_all.data(), sizeof(float) * vtx_all.size());
+        d.idx = (const int32_t *)upload(idx_all.data(), sizeof(int32_t) * idx_all.size());
+        d.wnodes = (const float4 *)upload(wnodes_all.data(), sizeof(WideNode) * wnodes_all.size());
+        d.wtris = (const float4 *)upload(wtris_all.data(), sizeof(TriRecord) * wtris_all.size());
+        d.stris = (const float4 *)upload(stris.data(), sizeof(TriRecord) * stris.size());
+        d.mat_ids = (const int32_t *)upload(mids.data(), sizeof(int32_t) * mids.size());
+        d.materials = (const pt_material *)upload(mats.data(), sizeof(pt_material) * mats.size());
+        d.light_tri = nullptr;
+        d.light_cdf = nullptr;
+        if (!light_tri.empty()) {
+            d.light_tri = (const int32_t *)upload(light_tri.data(), sizeof(int32_t) * light_tri.size());
+            d.light_cdf = (const float *)upload(light_cdf.data(), sizeof(float) * light_cdf.size());
+        }
+        d.n_lights = (uint32_t)light_tri.size();
+        d.light_area = light_cdf.empty() ? 0.f : light_cdf.back();
+        d.n_nodes = (uint32_t)nodes_all.size();
+        d.n_tri = (uint32_t)total_tris;
+        d.n_wnodes = (uint32_t)wnodes_all.size();
+        d.n_materials = (uint32_t)mats.size();
+        d.link_enc = link_encoding;
+        d.wide_depth = wide_depth;
+        d.tlas = (const float4 *)upload(top_nodes, sizeof(pt_bbox) * (size_t)n_top_nodes);
+        d.instances = (const DeviceInstance *)upload(dinst.data(), sizeof(DeviceInstance) * dinst.size());
+        d.n_tlas_nodes = n_top_nodes;
+        d.n_instances = n_instances;
+        *out = sc.release();
+        return PT_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(PT_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception &err) {
+        return fail(PT_ERR_INVALID, err.what());
+    } catch (...) {
+        return fail(PT_ERR_INVALID, "unknown error");
+    }
+}
+
+uint32_t pt_scene_instance_count(const pt_scene *scene) { return scene ? scene->dev.n_instances : 0; }
+
+} // extern "C"

@@ -10,6 +10,16 @@ namespace mipt {
 
 struct DeviceBuffer;
 
+// One placed copy of a mesh in a two-level scene (80 bytes, read as five 16-byte words).
+struct DeviceInstance {
+    float inv[12];        // world -> object, 3 rows of (xyz | translation)
+    // Where the instance's mesh starts in the scene-wide arrays: skip-link nodes, two-child
+    // nodes, traversal triangle records, vertices, triangles (of idx); then its triangle
+    // count and the index of its first triangle in the world-space shading records.
+    uint32_t node_off, wnode_off, wtri_off, vtx_off;
+    uint32_t tri_off, n_tri, first_tri, _pad;
+};
+
 // Device-resident scene, passed to kernels by value.
 struct DeviceScene {
     // The three buffers the reference shader binds (shaders/RadeonRays/bvh.glslh:103-117).
@@ -32,6 +42,13 @@ struct DeviceScene {
     uint32_t n_nodes, n_tri, n_wnodes, n_materials;
     uint32_t link_enc;
     uint32_t wide_depth;
+    // Two-level scenes only (tlas != nullptr): a skip-link tree over the instances whose leaf
+    // payload is an instance index (the "top-level BVH" of src/bvh/bvh_builder.h:31); the
+    // arrays above then hold every mesh back to back, in object space, except stris, which
+    // holds one world-space record per instanced triangle.
+    const float4 *tlas;
+    const DeviceInstance *instances;
+    uint32_t n_tlas_nodes, n_instances;
 };
 
 // Device counters of a trace call (mirrors pt_trace_stats, device side).
@@ -62,6 +79,12 @@ void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *r
 void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                           uint64_t n, bool fixup, DeviceTraceCounters *counters,
                           bool count_work, const ExtendConfig &cfg, DeviceBuffer *sort_scratch);
+
+// Closest hit in a two-level scene (s.tlas set).  exact: meshes in the fixed skip-link order.
+// counters must be non-null (its tie_count is always written).
+void launch_trace_two_level(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
+                            uint64_t n, bool fixup, bool exact, DeviceTraceCounters *counters,
+                            bool count_work);
 
 // Workgroups of `block` threads a persistent kernel may launch and still have them all
 // resident: compute units x min(cap, what the occupancy query admits).

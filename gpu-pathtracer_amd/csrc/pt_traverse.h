@@ -489,6 +489,125 @@ __device__ __forceinline__ bool occluded_wide(const DeviceScene &s, const float4
     }
 }
 
+// ---- two-level scenes ------------------------------------------------------------------
+// The top level is walked in the reference's fixed skip-link order on the world-space ray
+// (same loop as IntersectSceneClosest, shaders/RadeonRays/bvh.glslh:431-455); a top-level leaf
+// names an instance (src/bvh/bvh_builder.h:31), whose mesh is then searched with the ray taken
+// to object space and the running nearest distance as its limit.  The ray parameter is the
+// same in both spaces (the direction is transformed, not renormalised).  Meshes are searched
+// with closest_hit / occluded_wide, i.e. with the reference's per-mesh result, so the whole
+// query equals the fixed-order walk of both levels.
+
+// One instance's mesh as a scene of its own; `ray` goes to its object space.
+__device__ __forceinline__ DeviceScene enter_instance(const DeviceScene &s, int32_t instance,
+                                                      float4 &ro, float4 &rd) {
+    const float4 *ip = reinterpret_cast<const float4 *>(s.instances + instance);
+    const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+    const uint4 o0 = reinterpret_cast<const uint4 *>(ip)[3];
+    const uint4 o1 = reinterpret_cast<const uint4 *>(ip)[4];
+    DeviceScene m = s;
+    m.nodes = s.nodes + 2 * (size_t)o0.x;
+    m.wnodes = s.wnodes + 4 * (size_t)o0.y;
+    m.wtris = s.wtris + 3 * (size_t)o0.z;
+    m.vtx = s.vtx + 3 * (size_t)o0.w;
+    m.idx = s.idx + 3 * (size_t)o1.x;
+    m.n_tri = o1.y;
+    const float ox = ro.x, oy = ro.y, oz = ro.z, dx = rd.x, dy = rd.y, dz = rd.z;
+    ro.x = ((r0.x * ox + r0.y * oy) + r0.z * oz) + r0.w;
+    ro.y = ((r1.x * ox + r1.y * oy) + r1.z * oz) + r1.w;
+    ro.z = ((r2.x * ox + r2.y * oy) + r2.z * oz) + r2.w;
+    rd.x = (r0.x * dx + r0.y * dy) + r0.z * dz;
+    rd.y = (r1.x * dx + r1.y * dy) + r1.z * dz;
+    rd.z = (r2.x * dx + r2.y * dy) + r2.z * dz;
+    return m;
+}
+
+__device__ __forceinline__ RayPre top_level_ray(const float4 ro, const float4 rd) {
+    RayPre r;
+    r.ox = ro.x; r.oy = ro.y; r.oz = ro.z;
+    r.ix = 1.0f / rd.x; r.iy = 1.0f / rd.y; r.iz = 1.0f / rd.z;   // bvh.glslh:421
+    r.sx = r.sy = r.sz = 0.f;
+    r.axis = 2;
+    return r;
+}
+
+// Closest hit: shapeid = instance, primid = triangle of the instance's mesh.  exact: meshes
+// by traverse_skiplink instead of closest_hit.  Returns whether any mesh search was a tie.
+template <bool COUNT>
+__device__ __forceinline__ bool closest_hit_two_level(const DeviceScene &s, const float4 ro,
+                                                      const float4 rd, int32_t *stack, bool fixup,
+                                                      bool exact, int32_t &shapeid,
+                                                      int32_t &primid, float &b0, float &b1,
+                                                      float &b2, float &t, unsigned long long &nb,
+                                                      unsigned long long &nt) {
+    const RayPre r = top_level_ray(ro, rd);
+    b0 = 0.f; b1 = 0.f; b2 = 0.f; t = ro.w;
+    shapeid = -1; primid = -1;
+    bool tie = false;
+    int32_t idx = 0;
+    while (idx != -1) {
+        const float4 lo = s.tlas[2 * (int64_t)idx + 0];
+        const float4 hi = s.tlas[2 * (int64_t)idx + 1];
+        if (COUNT) ++nb;
+        const int32_t link = decode_link(hi.w, s.link_enc);
+        float t0;
+        if (intersect_box(r, lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, t, t0)) {
+            const int32_t payload = decode_link(lo.w, s.link_enc);
+            if (payload != -1) {
+                float4 oo = ro, od = rd;
+                const DeviceScene m = enter_instance(s, payload, oo, od);
+                oo.w = t;
+                int32_t sid, pid;
+                float c0, c1, c2, ct;
+                if (exact)
+                    traverse_skiplink<false, COUNT>(m, oo, od, sid, pid, c0, c1, c2, ct, nb, nt);
+                else
+                    tie |= closest_hit<COUNT>(m, oo, od, stack, fixup, sid, pid, c0, c1, c2, ct, nb,
+                                              nt);
+                if (pid >= 0) {
+                    shapeid = payload; primid = pid;
+                    b0 = c0; b1 = c1; b2 = c2; t = ct;
+                }
+                idx = link;
+            } else {
+                ++idx;
+            }
+        } else {
+            idx = link;
+        }
+    }
+    return tie;
+}
+
+// Occlusion (IntersectSceneAny, bvh.glslh:378-414, over both levels).
+__device__ __forceinline__ bool occluded_two_level(const DeviceScene &s, const float4 ro,
+                                                   const float4 rd, int32_t *stack, bool exact) {
+    const RayPre r = top_level_ray(ro, rd);
+    int32_t idx = 0;
+    while (idx != -1) {
+        const float4 lo = s.tlas[2 * (int64_t)idx + 0];
+        const float4 hi = s.tlas[2 * (int64_t)idx + 1];
+        const int32_t link = decode_link(hi.w, s.link_enc);
+        float t0;
+        if (intersect_box(r, lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, ro.w, t0)) {
+            const int32_t payload = decode_link(lo.w, s.link_enc);
+            if (payload != -1) {
+                float4 oo = ro, od = rd;
+                const DeviceScene m = enter_instance(s, payload, oo, od);
+                const bool occ = (exact || m.n_tri < 2) ? occluded_skiplink(m, oo, od)
+                                                        : occluded_wide(m, oo, od, stack);
+                if (occ) return true;
+                idx = link;
+            } else {
+                ++idx;
+            }
+        } else {
+            idx = link;
+        }
+    }
+    return false;
+}
+
 __device__ __forceinline__ void count_ties(bool tie, unsigned int *tie_count) {
     const unsigned long long m = __ballot(tie);
     if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1)

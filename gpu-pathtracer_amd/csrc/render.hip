@@ -90,6 +90,39 @@ __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend(Devic
     }
 }
 
+// extend / occlude on a two-level scene: one thread per ray.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_pt_extend_two_level(DeviceScene s, const pt_ray *rays,
+                                                               pt_hit *hits,
+                                                               const unsigned int *count,
+                                                               unsigned int *tie_count,
+                                                               DeviceTraceCounters *work) {
+    __shared__ int32_t s_stack[kTraceStack * kBlock];
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t n = *count;
+    if ((uint64_t)blockIdx.x * kBlock >= n) return;
+    bool tie = false;
+    unsigned long long nb = 0, nt = 0;
+    if (i < n) {
+        const float4 ro = reinterpret_cast<const float4 *>(rays + i)[0];
+        const float4 rd = reinterpret_cast<const float4 *>(rays + i)[1];
+        float b0, b1, b2, t;
+        int32_t shapeid, primid;
+        tie = closest_hit_two_level<COUNT>(s, ro, rd, s_stack + threadIdx.x, true, false, shapeid,
+                                           primid, b0, b1, b2, t, nb, nt);
+        store_hit(hits, i, shapeid, primid, b0, b1, b2, t);
+    }
+    count_ties(tie, tie_count);
+    if (COUNT) {
+        nb = wave_sum(nb);
+        nt = wave_sum(nt);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&work->box_tests, nb);
+            atomicAdd(&work->tri_tests, nt);
+        }
+    }
+}
+
 // extend, persistent form: the grid is sized to the machine, not to the queue.  Queue
 // chunks of 64 rays are dealt round-robin to the waves (chunk c belongs to wave c % n_waves:
 // static, so no work-distribution atomics), and a wave tops its idle lanes up from its own
@@ -137,7 +170,10 @@ __global__ __launch_bounds__(kWideBlock) void k_pt_shade(DeviceScene s, RenderLa
                       thr.z * rl.p.background[2]);
         } else {
             const float4 rd4 = reinterpret_cast<const float4 *>(ws.rays[buf_in] + i)[1];
-            const TriVerts tv = fetch_tri(s.stris, hi.y);
+            // two-level scenes: hi.x names the instance, hi.y the triangle of its mesh; the
+            // shading records are per instanced triangle, in world space
+            const int32_t tri = s.tlas ? (int32_t)(s.instances[hi.x].first_tri + (uint32_t)hi.y) : hi.y;
+            const TriVerts tv = fetch_tri(s.stris, tri);
             const pt_material m = s.materials[tv.material];
             LightList lights;
             lights.tri = s.light_tri;
@@ -223,6 +259,18 @@ __global__ __launch_bounds__(kBlock) void k_pt_occlude(DeviceScene s, RenderWork
     ShadowSink{ws.shadow_carry, ws.radiance}((uint32_t)i, occ);
 }
 
+__global__ __launch_bounds__(kBlock) void k_pt_occlude_two_level(DeviceScene s, RenderWorkspace ws,
+                                                                 const unsigned int *count) {
+    __shared__ int32_t s_stack[kTraceStack * kBlock];
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t n = *count;
+    if (i >= n) return;
+    const float4 ro = reinterpret_cast<const float4 *>(ws.shadow_rays + i)[0];
+    const float4 rd = reinterpret_cast<const float4 *>(ws.shadow_rays + i)[1];
+    const bool occ = occluded_two_level(s, ro, rd, s_stack + threadIdx.x, false);
+    ShadowSink{ws.shadow_carry, ws.radiance}((uint32_t)i, occ);
+}
+
 // Persistent waves with lane refill and step voting, as the closest-hit kernel.
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_persistent(
     DeviceScene s, RenderWorkspace ws, const unsigned int *count, int refill, int leaf_lanes) {
@@ -296,6 +344,15 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
                       const unsigned int *count, uint64_t max_rays, unsigned int *tie_count,
                       DeviceTraceCounters *work, const ExtendConfig &cfg) {
     if (!max_rays) return;
+    if (s.tlas) {
+        if (work)
+            hipLaunchKernelGGL(k_pt_extend_two_level<true>, dim3(blocks(max_rays, kBlock)),
+                               dim3(kBlock), 0, st, s, ws.rays[buf], ws.hits, count, tie_count, work);
+        else
+            hipLaunchKernelGGL(k_pt_extend_two_level<false>, dim3(blocks(max_rays, kBlock)),
+                               dim3(kBlock), 0, st, s, ws.rays[buf], ws.hits, count, tie_count, work);
+        return;
+    }
     if (cfg.persistent_blocks > 0) {
         static int occ[2] = {0, 0};
         const void *k = work ? (const void *)k_pt_extend_persistent<true>
@@ -331,6 +388,11 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
                        const unsigned int *shadow_count, uint64_t max_rays,
                        const ExtendConfig &cfg) {
     if (!max_rays) return;
+    if (s.tlas) {
+        hipLaunchKernelGGL(k_pt_occlude_two_level, dim3(blocks(max_rays, kBlock)), dim3(kBlock), 0,
+                           st, s, ws, shadow_count);
+        return;
+    }
     if (cfg.persistent_blocks > 0) {
         static int occ = 0;
         const unsigned int grid = (unsigned int)std::min<uint64_t>(

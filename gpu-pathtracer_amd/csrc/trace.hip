@@ -105,6 +105,47 @@ __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_persi
                                      nullptr, nullptr, OccludedSink{occluded});
 }
 
+// Two-level scenes: one thread per ray (see closest_hit_two_level).
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_two_level(DeviceScene s, const pt_ray *rays,
+                                                           pt_hit *hits, uint64_t n, bool fixup,
+                                                           bool exact,
+                                                           DeviceTraceCounters *counters) {
+    __shared__ int32_t s_stack[kTraceStack * kBlock];
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    unsigned long long nb = 0, nt = 0;
+    bool tie = false;
+    if (i < n) {
+        const float4 ro = reinterpret_cast<const float4 *>(rays + i)[0];
+        const float4 rd = reinterpret_cast<const float4 *>(rays + i)[1];
+        float b0, b1, b2, t;
+        int32_t shapeid, primid;
+        tie = closest_hit_two_level<COUNT>(s, ro, rd, s_stack + threadIdx.x, fixup, exact, shapeid,
+                                           primid, b0, b1, b2, t, nb, nt);
+        store_hit(hits, i, shapeid, primid, b0, b1, b2, t);
+    }
+    count_ties(tie, &counters->tie_count);
+    if (COUNT) {
+        nb = wave_sum(nb);
+        nt = wave_sum(nt);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&counters->box_tests, nb);
+            atomicAdd(&counters->tri_tests, nt);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_trace_any_two_level(DeviceScene s, const pt_ray *rays,
+                                                               int32_t *occluded, uint64_t n,
+                                                               bool exact) {
+    __shared__ int32_t s_stack[kTraceStack * kBlock];
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 ro = reinterpret_cast<const float4 *>(rays + i)[0];
+    const float4 rd = reinterpret_cast<const float4 *>(rays + i)[1];
+    occluded[i] = occluded_two_level(s, ro, rd, s_stack + threadIdx.x, exact) ? 1 : 0;
+}
+
 // Sort key of a ray: 30-bit Morton code of its origin's cell in a 1024^3 grid over the scene's
 // root box.  Rays that start close together walk the same part of the tree; on scenes much
 // larger than the caches that is worth more than the sort costs.
@@ -171,10 +212,26 @@ void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *r
     }
 }
 
+void launch_trace_two_level(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
+                            uint64_t n, bool fixup, bool exact, DeviceTraceCounters *counters,
+                            bool count_work) {
+    if (n == 0) return;
+    if (count_work)
+        hipLaunchKernelGGL((k_trace_two_level<true>), dim3(grid_for(n)), dim3(kBlock), 0, st, s,
+                           rays, hits, n, fixup, exact, counters);
+    else
+        hipLaunchKernelGGL((k_trace_two_level<false>), dim3(grid_for(n)), dim3(kBlock), 0, st, s,
+                           rays, hits, n, fixup, exact, counters);
+}
+
 void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                           uint64_t n, bool fixup, DeviceTraceCounters *counters,
                           bool count_work, const ExtendConfig &cfg, DeviceBuffer *sort_scratch) {
     if (n == 0) return;
+    if (s.tlas) {
+        launch_trace_two_level(st, s, rays, hits, n, fixup, false, counters, count_work);
+        return;
+    }
     if (cfg.persistent_blocks > 0) {
         const uint32_t *perm = nullptr;
         if (cfg.sort_rays && sort_scratch) {
@@ -220,6 +277,11 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
 void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, int32_t *occluded,
                       uint64_t n, bool exact_order, const ExtendConfig &cfg) {
     if (n == 0) return;
+    if (s.tlas) {
+        hipLaunchKernelGGL(k_trace_any_two_level, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays,
+                           occluded, n, exact_order);
+        return;
+    }
     const bool wide = !exact_order && s.n_tri >= 2;
     if (wide && cfg.persistent_blocks > 0) {
         static int occ = 0;

@@ -85,6 +85,11 @@ void build_light_list(const float *vtx, const int32_t *idx, uint32_t n_tri,
                       const pt_material *materials, const int32_t *material_ids,
                       std::vector<int32_t> &tri, std::vector<float> &cdf);
 
+// Two-level scenes (instances.cpp).  m, inv: 3x4, three rows of (linear part | translation).
+bool invert_affine(const float m[12], float inv[12]);           // false: singular or non-finite
+void transform_point(const float m[12], const float p[3], float out[3]);
+void instance_world_box(const float m[12], const pt_bbox &root, pt_bbox &out);
+
 // String-keyed options as the reference sets them on RadeonRays::Options
 // (src/bvh/bvh_builder.cpp:18-32, src/main_granite.cpp:175-176).
 bool set_option(pt_bvh_options &opt, const std::string &key, const std::string &value,

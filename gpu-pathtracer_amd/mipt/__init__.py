@@ -81,6 +81,17 @@ class RenderStats(C.Structure):
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64)]
 
 
+class MeshDesc(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("vertices", C.c_void_p), ("indices", C.c_void_p),
+                ("material_ids", C.c_void_p), ("n_nodes", C.c_uint32), ("n_vertices", C.c_uint32),
+                ("n_triangles", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class Instance(C.Structure):
+    _fields_ = [("object_to_world", C.c_float * 12), ("mesh", C.c_uint32),
+                ("material_offset", C.c_int32)]
+
+
 class MiptError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"[{code}] {message}")
@@ -127,6 +138,12 @@ _PROTOS = {
     "pt_scene_destroy": (C.c_int, [_vp]),
     "pt_scene_build": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint32, _vp,
                                  C.c_uint32, C.POINTER(_vp)]),
+    "pt_instance_bounds": (C.c_int, [C.POINTER(MeshDesc), C.c_uint32, C.POINTER(Instance),
+                                     C.c_uint32, _vp]),
+    "pt_scene_create_instanced": (C.c_int, [_vp, C.POINTER(MeshDesc), C.c_uint32,
+                                            C.POINTER(Instance), C.c_uint32, _vp, C.c_uint32,
+                                            C.c_uint32, _vp, C.c_uint32, C.POINTER(_vp)]),
+    "pt_scene_instance_count": (C.c_uint32, [_vp]),
     "pt_scene_node_count": (C.c_uint32, [_vp]),
     "pt_scene_link_encoding": (C.c_uint32, [_vp]),
     "pt_scene_read_nodes": (C.c_int, [_vp, _vp]),
@@ -377,6 +394,28 @@ class Scene:
                                    mats.shape[0] if mats is not None else 0,
                                    _ptr(mids) if mids is not None else None, C.byref(self._h)))
 
+    @classmethod
+    def instanced(cls, ctx: Context, meshes, transforms, mesh_of, top_nodes, materials=None,
+                  material_offsets=None, link_encoding: int = PT_LINKS_FLOAT_VALUE) -> "Scene":
+        """``pt_scene_create_instanced``.  meshes: [(nodes, vtx, idx, material_ids or None)];
+        transforms: [n, 3, 4] object-to-world; mesh_of: mesh index per instance; top_nodes:
+        skip-link tree over ``instance_bounds(...)``."""
+        descs, insts, keep = _instance_args(meshes, transforms, mesh_of, material_offsets)
+        top = _as(top_nodes, bbox_dtype, "top_nodes")
+        mats = _as(materials, material_dtype, "materials") if materials is not None else None
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self._h = _vp()
+        _check(lib.pt_scene_create_instanced(
+            ctx._h, descs, len(descs), insts, len(insts), _ptr(top), top.shape[0], link_encoding,
+            _ptr(mats) if mats is not None else None, mats.shape[0] if mats is not None else 0,
+            C.byref(self._h)))
+        self.n_tri = sum(int(descs[m].n_triangles) for m in mesh_of)
+        return self
+
+    def instance_count(self) -> int:
+        return int(lib.pt_scene_instance_count(self._h))
+
     def read_nodes(self) -> np.ndarray:
         """The scene's skip-link node array."""
         out = np.empty(lib.pt_scene_node_count(self._h), dtype=bbox_dtype)
@@ -422,6 +461,46 @@ class Scene:
 
     def trace_any_device(self, rays_dev: int, n: int, out_dev: int) -> None:
         _check(lib.pt_trace_any_device(self.ctx._h, self._h, rays_dev, n, out_dev))
+
+
+def _instance_args(meshes, transforms, mesh_of, material_offsets=None):
+    keep = []
+    descs = (MeshDesc * len(meshes))()
+    for k, mesh in enumerate(meshes):
+        nodes, vtx, idx = mesh[0], mesh[1], mesh[2]
+        mids = mesh[3] if len(mesh) > 3 else None
+        nodes = _as(nodes, bbox_dtype, "nodes")
+        vtx = _as(vtx, np.float32, "vtx").reshape(-1, 3)
+        idx = _as(idx, np.int32, "idx").reshape(-1, 3)
+        keep += [nodes, vtx, idx]
+        descs[k].nodes, descs[k].vertices, descs[k].indices = _ptr(nodes), _ptr(vtx), _ptr(idx)
+        descs[k].n_nodes, descs[k].n_vertices, descs[k].n_triangles = \
+            nodes.shape[0], vtx.shape[0], idx.shape[0]
+        if mids is not None:
+            mids = _as(mids, np.int32, "material_ids")
+            if mids.shape[0] != idx.shape[0]:
+                raise ValueError("material_ids must have one entry per triangle")
+            keep.append(mids)
+            descs[k].material_ids = _ptr(mids)
+    tr = _as(transforms, np.float32, "transforms").reshape(-1, 12)
+    if tr.shape[0] != len(mesh_of):
+        raise ValueError("one transform per instance")
+    insts = (Instance * len(mesh_of))()
+    for k, m in enumerate(mesh_of):
+        for j in range(12):
+            insts[k].object_to_world[j] = float(tr[k, j])
+        insts[k].mesh = int(m)
+        insts[k].material_offset = int(material_offsets[k]) if material_offsets is not None else 0
+    descs._keep = keep
+    return descs, insts, keep
+
+
+def instance_bounds(meshes, transforms, mesh_of) -> np.ndarray:
+    """``pt_instance_bounds``: world-space leaf boxes for the top-level ``build_bvh``."""
+    descs, insts, _keep = _instance_args(meshes, transforms, mesh_of)
+    out = np.zeros(len(insts), dtype=bbox_dtype)
+    _check(lib.pt_instance_bounds(descs, len(descs), insts, len(insts), _ptr(out)))
+    return out
 
 
 def shard_layout(width: int, height: int, tile_size: int, shard_index: int, shard_count: int):

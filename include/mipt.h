@@ -212,6 +212,46 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
 int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int32_t *idx,
                    uint32_t n_tri, const pt_material *materials, uint32_t n_materials,
                    const int32_t *material_ids, uint32_t link_encoding, pt_scene **out);
+/* ---- two-level scenes: meshes placed by affine transforms ---------------------------------
+ * The format the reference documents for a "top-level BVH" whose leaf payload is an instance
+ * index (src/bvh/bvh_builder.h:29-33) and never builds (its two-level translator is disabled,
+ * src/bvh/RadeonRays/plain_bvh_translator.cpp:98-101,134-137).  Every tree comes from
+ * pt_bvh_build, like the reference's single one: one per mesh over its triangles' boxes, one
+ * over the instances' world boxes from pt_instance_bounds.
+ *
+ * Semantics.  The top level is walked like IntersectSceneClosest walks its nodes
+ * (shaders/RadeonRays/bvh.glslh:431-455) with the world-space ray; at a leaf the ray goes to
+ * the instance's object space (o' = W o + w, d' = W d in binary32, ((a+b)+c)+d order, W|w the
+ * inverse of object_to_world computed in binary64 and rounded once) and the mesh is searched
+ * with the running nearest distance as limit; d' is not renormalised, so distances are the
+ * same in both spaces.  A hit reports shapeid = instance index and primid = triangle of the
+ * instance's mesh.  Shading uses the world-space vertices M v (same operation order). */
+typedef struct pt_mesh_desc {
+    const pt_bbox *nodes;        /* the mesh's skip-link BVH, as for pt_scene_create */
+    const float *vertices;       /* xyz packed, object space */
+    const int32_t *indices;      /* 3 per triangle */
+    const int32_t *material_ids; /* per triangle, or NULL (all 0) */
+    uint32_t n_nodes, n_vertices, n_triangles, _pad;
+} pt_mesh_desc;
+typedef struct pt_instance {
+    float object_to_world[12];   /* 3 rows of (linear part | translation) */
+    uint32_t mesh;
+    int32_t material_offset;     /* added to the mesh's material ids */
+} pt_instance;
+/* World-space box of every instance (the eight corners of its mesh's root box, transformed):
+ * the leaf boxes of the top-level build.  Host only. */
+int pt_instance_bounds(const pt_mesh_desc *meshes, uint32_t n_meshes, const pt_instance *instances,
+                       uint32_t n_instances, pt_bbox *out);
+/* top_nodes: skip-link tree over the instances (leaf payload = instance index), all trees in
+ * the same link_encoding.  materials may be NULL (one grey diffuse material).  The scene
+ * works with every pt_trace_* and pt_render call (PT_TRACE_MOLLER_TRUMBORE excepted). */
+int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint32_t n_meshes,
+                              const pt_instance *instances, uint32_t n_instances,
+                              const pt_bbox *top_nodes, uint32_t n_top_nodes,
+                              uint32_t link_encoding, const pt_material *materials,
+                              uint32_t n_materials, pt_scene **out);
+uint32_t pt_scene_instance_count(const pt_scene *scene);   /* 0 for a single-level scene */
+
 /* The scene's skip-link array (what pt_scene_create was given, or what pt_scene_build made):
  * for validation, caching, or a CPU traversal of the same tree.  Blocking. */
 uint32_t pt_scene_node_count(const pt_scene *scene);

@@ -67,6 +67,12 @@ def lib():
             "o_intersect_triangle_watertight": (C.c_int, [vp, vp, vp, vp, vp]),
             "o_intersect_triangle_mt": (C.c_int, [vp, vp, vp, vp, vp]),
             "o_precompute_ray": (None, [vp, vp]),
+            "o_invert_affine": (C.c_int, [vp, vp]),
+            "o_transform_points": (None, [vp, vp, C.c_uint64, vp]),
+            "o_instance_bounds": (None, [vp, vp, vp]),
+            "o_two_level_closest_batch": (None, [vp, vp, vp, vp, C.c_uint64, vp,
+                                                 C.POINTER(Counters), C.c_int]),
+            "o_two_level_any_batch": (None, [vp, vp, vp, vp, C.c_uint64, vp, C.c_int]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(_lib, name)
@@ -203,6 +209,116 @@ def render(nodes, vtx, idx, materials, material_ids, cam, params, film=None, rec
                        mids.ctypes.data, C.addressof(cam), C.addressof(params), x0, y0, x1, y1,
                        film.ctypes.data, nthreads, idx.shape[0])
     return film, int(rays)
+
+
+# ---- two-level scenes --------------------------------------------------------------------
+class _OMesh(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("vertices", C.c_void_p), ("indices", C.c_void_p)]
+
+
+class _OInstance(C.Structure):
+    _fields_ = [("inv", C.c_float * 12), ("mesh", C.c_int32), ("pad", C.c_int32 * 3)]
+
+
+def invert_affine(m) -> np.ndarray:
+    m = _c(m, np.float32).reshape(12)
+    out = np.empty(12, dtype=np.float32)
+    if not lib().o_invert_affine(m.ctypes.data, out.ctypes.data):
+        raise ValueError("singular transform")
+    return out.reshape(3, 4)
+
+
+def transform_points(m, p) -> np.ndarray:
+    m = _c(m, np.float32).reshape(12)
+    p = _c(p, np.float32).reshape(-1, 3)
+    out = np.empty_like(p)
+    lib().o_transform_points(m.ctypes.data, p.ctypes.data, p.shape[0], out.ctypes.data)
+    return out
+
+
+class TwoLevel:
+    """meshes: [(nodes, vtx, idx)], each with its own skip-link tree; transforms: [n, 3, 4]
+    object-to-world; mesh_of: mesh index per instance; top: skip-link tree over the instances
+    (None until bounds() has been used to build it; assign .top)."""
+
+    def __init__(self, meshes, transforms, mesh_of, top=None):
+        self.meshes = [(_c(n, bbox_dtype), _c(v, np.float32).reshape(-1, 3),
+                        _c(i, np.int32).reshape(-1, 3)) for n, v, i in meshes]
+        self.transforms = _c(transforms, np.float32).reshape(-1, 3, 4)
+        self.mesh_of = [int(m) for m in mesh_of]
+        assert len(self.mesh_of) == self.transforms.shape[0]
+        self.top = None if top is None else _c(top, bbox_dtype)
+        self._m = (_OMesh * len(self.meshes))()
+        for k, (n, v, i) in enumerate(self.meshes):
+            self._m[k].nodes, self._m[k].vertices, self._m[k].indices = \
+                n.ctypes.data, v.ctypes.data, i.ctypes.data
+        self._i = (_OInstance * len(self.mesh_of))()
+        for k, m in enumerate(self.mesh_of):
+            inv = invert_affine(self.transforms[k]).reshape(12)
+            for j in range(12):
+                self._i[k].inv[j] = float(inv[j])
+            self._i[k].mesh = m
+
+    def bounds(self) -> np.ndarray:
+        """World-space leaf boxes of the instances, for the top-level build."""
+        out = np.zeros(len(self.mesh_of), dtype=bbox_dtype)
+        L = lib()
+        for k, m in enumerate(self.mesh_of):
+            t = _c(self.transforms[k], np.float32).reshape(12)
+            L.o_instance_bounds(t.ctypes.data, self.meshes[m][0][:1].ctypes.data,
+                                out[k:k + 1].ctypes.data)
+        return out
+
+    def world_triangles(self):
+        """(vtx [3T,3], idx [T,3], first_tri [n_instances]): every instanced triangle in
+        world space, instance after instance -- what shading reads."""
+        vs, first, n = [], [], 0
+        for k, m in enumerate(self.mesh_of):
+            _, v, i = self.meshes[m]
+            vs.append(transform_points(self.transforms[k], v[i.reshape(-1)]))
+            first.append(n)
+            n += i.shape[0]
+        vtx = np.concatenate(vs, axis=0)
+        idx = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+        return vtx, idx, np.asarray(first, dtype=np.uint32)
+
+    def closest(self, rays, nthreads=1, counters=False):
+        rays = _c(rays, ray_dtype)
+        out = np.empty(rays.shape[0], dtype=isect_dtype)
+        cnt = Counters(0, 0)
+        lib().o_two_level_closest_batch(self.top.ctypes.data, C.addressof(self._m),
+                                        C.addressof(self._i), rays.ctypes.data, rays.shape[0],
+                                        out.ctypes.data, C.byref(cnt), nthreads)
+        return (out, (cnt.box_tests, cnt.tri_tests)) if counters else out
+
+    def any_hit(self, rays, nthreads=1) -> np.ndarray:
+        rays = _c(rays, ray_dtype)
+        out = np.empty(rays.shape[0], dtype=np.int32)
+        lib().o_two_level_any_batch(self.top.ctypes.data, C.addressof(self._m),
+                                    C.addressof(self._i), rays.ctypes.data, rays.shape[0],
+                                    out.ctypes.data, nthreads)
+        return out
+
+    def render(self, materials, material_ids, cam, params, film=None, rect=None, nthreads=1):
+        """As render(); material_ids has one entry per instanced triangle (world_triangles
+        order)."""
+        L = lib()
+        L.os_render_two_level.restype = C.c_uint64
+        L.os_render_two_level.argtypes = [C.c_void_p] * 10 + [C.c_uint32] * 4 + \
+            [C.c_void_p, C.c_int, C.c_uint32]
+        vtx, idx, first = self.world_triangles()
+        mats, mids = _c(materials, material_dtype), _c(material_ids, np.int32)
+        assert mids.shape[0] == idx.shape[0]
+        W, H = params.width, params.height
+        if film is None:
+            film = np.zeros((H, W, 4), dtype=np.float32)
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, W, H)
+        rays = L.os_render_two_level(self.top.ctypes.data, C.addressof(self._m),
+                                     C.addressof(self._i), first.ctypes.data, vtx.ctypes.data,
+                                     idx.ctypes.data, mats.ctypes.data, mids.ctypes.data,
+                                     C.addressof(cam), C.addressof(params), x0, y0, x1, y1,
+                                     film.ctypes.data, nthreads, idx.shape[0])
+        return film, int(rays)
 
 
 def sincos_2pi(u):

@@ -257,6 +257,163 @@ int o_intersect_scene_any(const o_bbox *nodes, const float *vertices, const int3
     return 0;
 }
 
+/* ---- two-level scenes (specification of this project; see pt_oracle.h) ---------------- */
+int o_invert_affine(const float m[12], float inv[12])
+{
+    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9],
+                 i = m[10];
+    const double tx = m[3], ty = m[7], tz = m[11];
+    const double A = e * i - f * h, B = f * g - d * i, C = d * h - e * g;
+    const double det = (a * A + b * B) + c * C;
+    if (!(fabs(det) > 0.0) || !isfinite(det)) return 0;
+    const double r[3][3] = {
+        { A / det, (c * h - b * i) / det, (b * f - c * e) / det },
+        { B / det, (a * i - c * g) / det, (c * d - a * f) / det },
+        { C / det, (b * g - a * h) / det, (a * e - b * d) / det },
+    };
+    for (int k = 0; k < 3; ++k) {
+        inv[4 * k + 0] = (float)r[k][0];
+        inv[4 * k + 1] = (float)r[k][1];
+        inv[4 * k + 2] = (float)r[k][2];
+        inv[4 * k + 3] = (float)(-((r[k][0] * tx + r[k][1] * ty) + r[k][2] * tz));
+    }
+    for (int k = 0; k < 12; ++k)
+        if (!isfinite(inv[k])) return 0;
+    return 1;
+}
+
+static void transform_point(const float m[12], const float p[3], float out[3])
+{
+    for (int k = 0; k < 3; ++k)
+        out[k] = ((m[4 * k + 0] * p[0] + m[4 * k + 1] * p[1]) + m[4 * k + 2] * p[2]) + m[4 * k + 3];
+}
+
+void o_transform_points(const float m[12], const float *p, uint64_t n, float *out)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        float w[3];
+        transform_point(m, p + 3 * i, w);
+        out[3 * i + 0] = w[0]; out[3 * i + 1] = w[1]; out[3 * i + 2] = w[2];
+    }
+}
+
+void o_instance_bounds(const float m[12], const o_bbox *root, o_bbox *out)
+{
+    for (int k = 0; k < 3; ++k) { out->pmin[k] = INFINITY; out->pmax[k] = -INFINITY; }
+    out->pmin[3] = out->pmax[3] = 0.0f;
+    for (int corner = 0; corner < 8; ++corner) {
+        const float p[3] = { (corner & 1) ? root->pmax[0] : root->pmin[0],
+                             (corner & 2) ? root->pmax[1] : root->pmin[1],
+                             (corner & 4) ? root->pmax[2] : root->pmin[2] };
+        float w[3];
+        transform_point(m, p, w);
+        for (int k = 0; k < 3; ++k) {
+            out->pmin[k] = fminf(out->pmin[k], w[k]);
+            out->pmax[k] = fmaxf(out->pmax[k], w[k]);
+        }
+    }
+}
+
+static void to_object_space(const o_instance *in, const o_ray *r, o_ray *out)
+{
+    const float *m = in->inv;
+    for (int k = 0; k < 3; ++k) {
+        out->o[k] = ((m[4 * k + 0] * r->o[0] + m[4 * k + 1] * r->o[1]) + m[4 * k + 2] * r->o[2]) + m[4 * k + 3];
+        out->d[k] = (m[4 * k + 0] * r->d[0] + m[4 * k + 1] * r->d[1]) + m[4 * k + 2] * r->d[2];
+    }
+    out->o[3] = r->o[3];
+    out->d[3] = r->d[3];
+}
+
+void o_two_level_closest(const o_bbox *top, const o_mesh *meshes, const o_instance *instances,
+                         const o_ray *r, o_isect *isect, o_counters *cnt)
+{
+    const float invdir[3] = { 1.0f / r->d[0], 1.0f / r->d[1], 1.0f / r->d[2] };
+    isect->uvwt[0] = 0.0f; isect->uvwt[1] = 0.0f; isect->uvwt[2] = 0.0f; isect->uvwt[3] = r->o[3];
+    isect->shapeid = -1;
+    isect->primid = -1;
+    isect->pad0 = 667;
+    isect->pad1 = 0;
+    uint64_t nb = 0;
+    int32_t idx = 0;
+    while (idx != -1) {                                     /* the loop of bvh.glslh:431-455 */
+        const o_bbox *node = &top[idx];
+        ++nb;
+        if (o_intersect_box(r, invdir, node, isect->uvwt[3])) {
+            if (node_is_leaf(node)) {
+                const int32_t inst = (int32_t)node_startidx(node);
+                const o_instance *in = &instances[inst];
+                const o_mesh *mesh = &meshes[in->mesh];
+                o_ray lr;
+                to_object_space(in, r, &lr);
+                lr.o[3] = isect->uvwt[3];                   /* running nearest distance */
+                o_isect h;
+                o_intersect_scene_closest(mesh->nodes, mesh->vertices, mesh->indices, &lr, &h, cnt);
+                if (h.primid >= 0) {
+                    *isect = h;
+                    isect->shapeid = inst;
+                }
+                idx = (int32_t)node->pmax[3];
+            } else {
+                ++idx;
+            }
+        } else {
+            idx = (int32_t)node->pmax[3];
+        }
+    }
+    if (cnt) cnt->box_tests += nb;
+}
+
+int o_two_level_any(const o_bbox *top, const o_mesh *meshes, const o_instance *instances,
+                    const o_ray *r)
+{
+    const float invdir[3] = { 1.0f / r->d[0], 1.0f / r->d[1], 1.0f / r->d[2] };
+    int32_t idx = 0;
+    while (idx != -1) {                                     /* the loop of bvh.glslh:383-411 */
+        const o_bbox *node = &top[idx];
+        if (o_intersect_box(r, invdir, node, r->o[3])) {
+            if (node_is_leaf(node)) {
+                const o_instance *in = &instances[(int32_t)node_startidx(node)];
+                const o_mesh *mesh = &meshes[in->mesh];
+                o_ray lr;
+                to_object_space(in, r, &lr);
+                if (o_intersect_scene_any(mesh->nodes, mesh->vertices, mesh->indices, &lr))
+                    return 1;
+                idx = (int32_t)node->pmax[3];
+            } else {
+                ++idx;
+            }
+        } else {
+            idx = (int32_t)node->pmax[3];
+        }
+    }
+    return 0;
+}
+
+void o_two_level_closest_batch(const o_bbox *top, const o_mesh *meshes,
+                               const o_instance *instances, const o_ray *rays, uint64_t n,
+                               o_isect *out, o_counters *cnt, int nthreads)
+{
+    uint64_t nb = 0, nt = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads) reduction(+ : nb, nt)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        o_counters c = { 0, 0 };
+        o_two_level_closest(top, meshes, instances, &rays[i], &out[i], &c);
+        nb += c.box_tests; nt += c.tri_tests;
+    }
+    if (cnt) { cnt->box_tests += nb; cnt->tri_tests += nt; }
+}
+
+void o_two_level_any_batch(const o_bbox *top, const o_mesh *meshes, const o_instance *instances,
+                           const o_ray *rays, uint64_t n, int32_t *out, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads)
+    for (int64_t i = 0; i < (int64_t)n; ++i)
+        out[i] = o_two_level_any(top, meshes, instances, &rays[i]);
+}
+
 void o_closest_batch(const o_bbox *nodes, const float *vertices, const int32_t *indices,
                      const o_ray *rays, uint64_t n, o_isect *out, o_counters *cnt, int nthreads)
 {

@@ -85,6 +85,34 @@ void o_closest_intbits_batch(const o_bbox *nodes, const float *vertices, const i
 void o_brute_closest_batch(const float *vertices, const int32_t *indices, uint32_t n_tri,
                            const o_ray *rays, uint64_t n, o_isect *out, int nthreads);
 
+/* --- two-level scenes ---------------------------------------------------
+ * The reference documents a top-level BVH whose leaf payload is an instance index
+ * (src/bvh/bvh_builder.h:29-33) but its code for one is disabled
+ * (src/bvh/RadeonRays/plain_bvh_translator.cpp:98-101,134-137) and no shader walks one, so
+ * this is a specification of this project, "parity unpinned" throughout: the top level is
+ * walked with the loop of IntersectSceneClosest / IntersectSceneAny on the world-space ray; a
+ * top-level leaf takes the ray to the instance's object space (direction not renormalised, so
+ * distances agree in both spaces) and runs the same loop on the mesh with the running nearest
+ * distance as the limit.  Hits report shapeid = instance, primid = triangle of its mesh. */
+typedef struct { const o_bbox *nodes; const float *vertices; const int32_t *indices; } o_mesh;
+typedef struct { float inv[12]; int32_t mesh; int32_t pad[3]; } o_instance;
+/* Inverse of a 3x4 transform (rows of linear part | translation): binary64 cofactors and
+ * determinant, one rounding per entry.  Returns 0 if singular. */
+int  o_invert_affine(const float m[12], float inv[12]);
+/* out = M p per point, ((a+b)+c)+d in binary32. */
+void o_transform_points(const float m[12], const float *p, uint64_t n, float *out);
+/* Box of the eight transformed corners of root. */
+void o_instance_bounds(const float m[12], const o_bbox *root, o_bbox *out);
+void o_two_level_closest(const o_bbox *top, const o_mesh *meshes, const o_instance *instances,
+                         const o_ray *r, o_isect *isect, o_counters *cnt);
+int  o_two_level_any(const o_bbox *top, const o_mesh *meshes, const o_instance *instances,
+                     const o_ray *r);
+void o_two_level_closest_batch(const o_bbox *top, const o_mesh *meshes,
+                               const o_instance *instances, const o_ray *rays, uint64_t n,
+                               o_isect *out, o_counters *cnt, int nthreads);
+void o_two_level_any_batch(const o_bbox *top, const o_mesh *meshes, const o_instance *instances,
+                           const o_ray *rays, uint64_t n, int32_t *out, int nthreads);
+
 /* --- raygen + debug shade ---------------------------------------------- */
 void o_raygen_reference(const o_camera *cam, uint32_t width, uint32_t height,
                         uint32_t px, uint32_t py, o_ray *out);

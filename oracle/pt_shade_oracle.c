@@ -382,8 +382,33 @@ static void camera_ray(const os_camera *cam, uint32_t width, uint32_t height, fl
     }
 }
 
+/* What rays are traced against.  Single level: nodes / vtx / idx as the reference binds them.
+ * Two levels (top != NULL): vtx / idx then hold the world-space copy of every instanced
+ * triangle, instance after instance (first_tri[i] = index of instance i's first one), which is
+ * what shading and light sampling read; intersection goes through the two-level walk. */
+typedef struct {
+    const o_bbox *nodes; const float *vtx; const int32_t *idx;
+    const o_bbox *top; const o_mesh *meshes; const o_instance *instances; const uint32_t *first_tri;
+} os_geom;
+
+static void geom_closest(const os_geom *g, const o_ray *r, o_isect *h)
+{
+    if (g->top) {
+        o_two_level_closest(g->top, g->meshes, g->instances, r, h, NULL);
+        if (h->primid >= 0) h->primid += (int32_t)g->first_tri[h->shapeid];
+    } else {
+        o_intersect_scene_closest(g->nodes, g->vtx, g->idx, r, h, NULL);
+    }
+}
+
+static int geom_any(const os_geom *g, const o_ray *r)
+{
+    return g->top ? o_two_level_any(g->top, g->meshes, g->instances, r)
+                  : o_intersect_scene_any(g->nodes, g->vtx, g->idx, r);   /* bvh.glslh:378-414 */
+}
+
 /* Radiance of one camera sample. */
-static v3 trace_path(const o_bbox *nodes, const float *vtx, const int32_t *idx,
+static v3 trace_path(const os_geom *g,
                      const os_material *mats, const int32_t *mat_ids, const os_camera *cam,
                      const os_params *P, uint32_t x, uint32_t y, uint32_t sample,
                      uint64_t *rays_traced, const os_lights *lights)
@@ -400,8 +425,10 @@ static v3 trace_path(const o_bbox *nodes, const float *vtx, const int32_t *idx,
     float q = -1.0f;
     for (uint32_t bounce = 0; bounce < P->max_depth; ++bounce) {
         o_isect h;
-        o_intersect_scene_closest(nodes, vtx, idx, &ray, &h, NULL);
+        geom_closest(g, &ray, &h);
         ++*rays_traced;
+        const float *vtx = g->vtx;
+        const int32_t *idx = g->idx;
         if (h.primid < 0) {
             L.x += thr.x * P->background[0];
             L.y += thr.y * P->background[1];
@@ -428,7 +455,7 @@ static v3 trace_path(const o_bbox *nodes, const float *vtx, const int32_t *idx,
                 o_ray sr;
                 sr.o[0] = nee.so.x; sr.o[1] = nee.so.y; sr.o[2] = nee.so.z; sr.o[3] = nee.smax;
                 sr.d[0] = nee.sd.x; sr.d[1] = nee.sd.y; sr.d[2] = nee.sd.z; sr.d[3] = 0.0f;
-                occluded = o_intersect_scene_any(nodes, vtx, idx, &sr);   /* bvh.glslh:378-414 */
+                occluded = geom_any(g, &sr);
                 ++*rays_traced;
             }
             if (!occluded) {
@@ -448,15 +475,14 @@ static v3 trace_path(const o_bbox *nodes, const float *vtx, const int32_t *idx,
  * rgb += radiance of samples sample_begin .. sample_begin+sample_count-1 in that order,
  * a += sample_count.  With OS_FLAG_DEPTH_GREY the pixel is overwritten with the reference's
  * grey (shaders/depth.frag:90-107).  Returns the number of rays traced. */
-uint64_t os_render(const o_bbox *nodes, const float *vtx, const int32_t *idx,
-                   const os_material *mats, const int32_t *mat_ids, const os_camera *cam,
-                   const os_params *P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
-                   float *film, int nthreads, uint32_t n_tri)
+static uint64_t render_geom(const os_geom *g, const os_material *mats, const int32_t *mat_ids,
+                            const os_camera *cam, const os_params *P, uint32_t x0, uint32_t y0,
+                            uint32_t x1, uint32_t y1, float *film, int nthreads, uint32_t n_tri)
 {
     uint64_t rays = 0;
     if (nthreads < 1) nthreads = 1;
     os_lights lights = { NULL, NULL, 0, 0.0f };
-    if (P->flags & OS_FLAG_NEE) build_lights(vtx, idx, n_tri, mats, mat_ids, &lights);
+    if (P->flags & OS_FLAG_NEE) build_lights(g->vtx, g->idx, n_tri, mats, mat_ids, &lights);
     const os_lights *LP = &lights;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+ : rays)
     for (int64_t y = y0; y < (int64_t)y1; ++y) {
@@ -466,13 +492,13 @@ uint64_t os_render(const o_bbox *nodes, const float *vtx, const int32_t *idx,
                 o_ray ray;
                 camera_ray(cam, P->width, P->height, (float)x + 0.5f, (float)y + 0.5f, &ray);
                 o_isect h;
-                o_intersect_scene_closest(nodes, vtx, idx, &ray, &h, NULL);
+                geom_closest(g, &ray, &h);
                 ++rays;
                 o_depth_shade(&h, f);
                 continue;
             }
             for (uint32_t s = 0; s < P->sample_count; ++s) {
-                const v3 L = trace_path(nodes, vtx, idx, mats, mat_ids, cam, P, x, (uint32_t)y,
+                const v3 L = trace_path(g, mats, mat_ids, cam, P, x, (uint32_t)y,
                                         P->sample_begin + s, &rays, LP);
                 f[0] += L.x;
                 f[1] += L.y;
@@ -484,6 +510,28 @@ uint64_t os_render(const o_bbox *nodes, const float *vtx, const int32_t *idx,
     free(lights.tri);
     free(lights.cdf);
     return rays;
+}
+
+uint64_t os_render(const o_bbox *nodes, const float *vtx, const int32_t *idx,
+                   const os_material *mats, const int32_t *mat_ids, const os_camera *cam,
+                   const os_params *P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                   float *film, int nthreads, uint32_t n_tri)
+{
+    const os_geom g = { nodes, vtx, idx, NULL, NULL, NULL, NULL };
+    return render_geom(&g, mats, mat_ids, cam, P, x0, y0, x1, y1, film, nthreads, n_tri);
+}
+
+/* The same renderer over a two-level scene.  world_vtx / world_idx / mat_ids describe the
+ * n_tri instanced triangles in world space, instance after instance (see os_geom). */
+uint64_t os_render_two_level(const o_bbox *top, const o_mesh *meshes, const o_instance *instances,
+                             const uint32_t *first_tri, const float *world_vtx,
+                             const int32_t *world_idx, const os_material *mats,
+                             const int32_t *mat_ids, const os_camera *cam, const os_params *P,
+                             uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, float *film,
+                             int nthreads, uint32_t n_tri)
+{
+    const os_geom g = { NULL, world_vtx, world_idx, top, meshes, instances, first_tri };
+    return render_geom(&g, mats, mat_ids, cam, P, x0, y0, x1, y1, film, nthreads, n_tri);
 }
 
 /* Exposed pieces for unit tests of the sampling routines. */

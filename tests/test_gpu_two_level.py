@@ -1,0 +1,117 @@
+"""Two-level scenes on the GPU against the CPU restatement, through the C ABI: hits bit for
+bit (instance, triangle, barycentrics, distance), occlusion, and the path tracer's film.  The
+specification is this project's own (the reference only documents the node format,
+src/bvh/bvh_builder.h:29-33): parity unpinned."""
+import numpy as np
+import pytest
+
+import two_level_util as tl
+from conftest import same_hits
+from test_gpu_render import REL_RMSE_TOL, rel_rmse
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(mipt, oracle, ctx, sc, builder="sah"):
+    opt = mipt.bvh_options(**{"bvh.builder": builder})
+    meshes = []
+    for v, i, mids in sc["meshes"]:
+        meshes.append((mipt.build_bvh(mipt.mesh_leaf_bounds(v, i), opt), v, i, mids))
+    top = mipt.build_bvh(mipt.instance_bounds(meshes, sc["transforms"], sc["mesh_of"]), opt)
+    t = oracle.TwoLevel([m[:3] for m in meshes], sc["transforms"], sc["mesh_of"], top)
+    scene = mipt.Scene.instanced(ctx, meshes, sc["transforms"], sc["mesh_of"], top,
+                                 materials=tl.materials(mipt),
+                                 material_offsets=sc["material_offsets"])
+    return t, scene
+
+
+@pytest.mark.parametrize("builder", ["sah", "median"])
+def test_closest_and_any_hits_are_bit_exact(mipt, oracle, gpu_ctx, builder):
+    sc = tl.scene()
+    t, scene = _build(mipt, oracle, gpu_ctx, sc, builder)
+    try:
+        assert scene.instance_count() == len(sc["mesh_of"])
+        rays = tl.rays_for(60000, 4, mipt.ray_dtype)
+        want, (nb, nt) = t.closest(rays, nthreads=8, counters=True)
+        got, st = scene.trace_closest(rays, stats=True)
+        bad = same_hits(got, want, nan_equal=True)
+        assert bad.size == 0, f"{bad.size} rays differ, first {bad[:5]}"
+        assert (got["primid"] >= 0).sum() > 20000
+        assert len(set(got["shapeid"][got["primid"] >= 0])) >= len(sc["mesh_of"]) - 1
+        assert st.box_tests > 0 and st.tri_tests > 0
+        print(f"{st.tie_rays} tie rays; boxes/ray {st.box_tests / rays.shape[0]:.1f} "
+              f"(fixed order {nb / rays.shape[0]:.1f}), triangles/ray {st.tri_tests / rays.shape[0]:.2f} "
+              f"(fixed order {nt / rays.shape[0]:.2f})")
+        exact = scene.trace_closest(rays, flags=mipt.PT_TRACE_EXACT_ORDER)
+        assert same_hits(exact, want, nan_equal=True).size == 0
+        np.testing.assert_array_equal(scene.trace_any(rays), t.any_hit(rays, nthreads=8))
+        gpu_ctx.set_option("any.exact_order", 1)
+        try:
+            np.testing.assert_array_equal(scene.trace_any(rays), t.any_hit(rays, nthreads=8))
+        finally:
+            gpu_ctx.set_option("any.exact_order", 0)
+        with pytest.raises(mipt.MiptError, match="two-level"):
+            scene.trace_closest(rays[:8], flags=mipt.PT_TRACE_MOLLER_TRUMBORE)
+        with pytest.raises(mipt.MiptError, match="two-level"):
+            scene.read_nodes()
+    finally:
+        scene.close()
+
+
+@pytest.mark.parametrize("flags", [0, "nee"])
+def test_render_matches_the_cpu_restatement(mipt, oracle, gpu_ctx, flags):
+    sc = tl.scene(n_blob_tris=200, n_blobs=7)
+    t, scene = _build(mipt, oracle, gpu_ctx, sc)
+    W, H = 96, 64
+    film = mipt.Film(gpu_ctx, W, H)
+    try:
+        cam = mipt.look_at_camera((0.0, 3.0, -14.0), (0.0, 0.5, 0.0), fovy_deg=45.0, aspect=W / H)
+        p = mipt.render_params(W, H, sample_count=6, max_depth=5, seed=21,
+                               flags=mipt.PT_RENDER_NEE if flags else 0,
+                               background=(0.05, 0.06, 0.08))
+        st = mipt.render(gpu_ctx, scene, cam, p, film, stats=True)
+        got = film.read()
+        want, rays = t.render(tl.materials(oracle), tl.flat_material_ids(sc), cam, p, nthreads=8)
+        err = rel_rmse(got[..., :3], want[..., :3])
+        assert err <= REL_RMSE_TOL, f"relative RMSE {err}"
+        assert st.rays_primary + st.rays_bounce + st.rays_shadow == rays
+        n_diff = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+        assert n_diff == 0, f"film differs from the CPU restatement in {n_diff} words"
+        assert got[..., :3].mean() > 0.01
+        if flags:
+            assert st.rays_shadow > 0
+        # the reference's grey view of the same scene
+        pd = mipt.render_params(W, H, flags=mipt.PT_RENDER_DEPTH_GREY)
+        film.clear()
+        mipt.render(gpu_ctx, scene, cam, pd, film)
+        grey, _ = t.render(tl.materials(oracle), tl.flat_material_ids(sc), cam, pd, nthreads=8)
+        np.testing.assert_array_equal(film.read().view(np.uint32), grey.view(np.uint32))
+    finally:
+        film.close()
+        scene.close()
+
+
+def test_bad_input_is_rejected(mipt, oracle, gpu_ctx):
+    sc = tl.scene(n_blob_tris=40, n_blobs=2)
+    opt = mipt.bvh_options()
+    meshes = [(mipt.build_bvh(mipt.mesh_leaf_bounds(v, i), opt), v, i, m) for v, i, m in sc["meshes"]]
+    top = mipt.build_bvh(mipt.instance_bounds(meshes, sc["transforms"], sc["mesh_of"]), opt)
+    mats = tl.materials(mipt)
+
+    def make(**kw):
+        args = dict(meshes=meshes, transforms=sc["transforms"], mesh_of=sc["mesh_of"], top_nodes=top,
+                    materials=mats, material_offsets=sc["material_offsets"])
+        args.update(kw)
+        return mipt.Scene.instanced(gpu_ctx, **args)
+
+    with pytest.raises(mipt.MiptError, match="names mesh"):
+        make(mesh_of=[99] + list(sc["mesh_of"][1:]))
+    flat = sc["transforms"].copy()
+    flat[2, :, 1] = 0                                      # a transform that squashes y
+    with pytest.raises(mipt.MiptError, match="not invertible"):
+        make(transforms=flat)
+    with pytest.raises(mipt.MiptError, match="material"):
+        make(material_offsets=[5] * len(sc["mesh_of"]))
+    with pytest.raises(mipt.MiptError, match="in no top-level leaf|references triangle|leaf"):
+        make(top_nodes=mipt.build_bvh(mipt.instance_bounds(meshes, sc["transforms"][:-1], sc["mesh_of"][:-1]), opt))
+    make().close()
