@@ -36,6 +36,20 @@ static void check(bool ok, const char *what) {
 int main() {
     std::mt19937 rng(7);
     std::uniform_real_distribution<float> U(-10.f, 10.f), S(-1.f, 1.f);
+    // transforms of two-level scenes
+    for (int rep = 0; rep < 200; ++rep) {
+        float m[12], inv[12];
+        for (float &x : m) x = U(rng);
+        if (rep % 50 == 0) for (int k = 0; k < 4; ++k) m[4 + k] = 2.f * m[k];   // singular
+        const bool ok = invert_affine(m, inv);
+        check(ok == (rep % 50 != 0), "invert_affine");
+        pt_bbox root{{-1.f, -2.f, -3.f, 0.f}, {1.f, 2.f, 3.f, 0.f}}, world;
+        instance_world_box(m, root, world);
+        const float p[3] = {0.5f, -1.f, 2.f};
+        float w[3];
+        transform_point(m, p, w);
+        for (int k = 0; k < 3; ++k) check(w[k] >= world.pmin[k] && w[k] <= world.pmax[k], "instance_world_box");
+    }
     for (uint32_t n : {1u, 2u, 3u, 17u, 1000u, 20000u}) {
         std::vector<float> vtx;
         std::vector<int32_t> idx;

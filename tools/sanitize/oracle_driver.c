@@ -120,6 +120,47 @@ static void run_scene(uint32_t n_tri, int use_sah, int nthreads)
     }
     for (uint32_t i = 0; i < 4u * W * H; ++i) CHECK(film[i] == film[i]);
 
+    /* the same mesh as a two-level scene: placed three times (one mirrored, two coincident) */
+    if (n_tri >= 2) {
+        const float tr[3][12] = {
+            { 1, 0, 0, 0.5f,  0, 1, 0, 0,  0, 0, 1, 0 },
+            { -0.7f, 0.2f, 0, -2.0f,  0.1f, 1.3f, 0.2f, 1.0f,  0, -0.3f, 0.9f, 0.5f },
+            { 1, 0, 0, 0.5f,  0, 1, 0, 0,  0, 0, 1, 0 },
+        };
+        o_mesh mesh = { nodes, vtx, idx };
+        o_instance inst[3];
+        o_bbox ib[3], top[5];
+        memset(inst, 0, sizeof inst);
+        for (int k = 0; k < 3; ++k) {
+            CHECK(o_invert_affine(tr[k], inst[k].inv));
+            o_instance_bounds(tr[k], &nodes[0], &ib[k]);
+        }
+        CHECK(o_build_bvh(ib, 3, 1, 64, 10.0f, top) == 0);
+        o_two_level_closest_batch(top, &mesh, inst, rays, n_rays, h0, &cnt, nthreads);
+        o_two_level_any_batch(top, &mesh, inst, rays, n_rays, any, nthreads);
+        float *wv = malloc(sizeof(float) * 9 * 3 * n_tri);
+        int32_t *wi = malloc(sizeof(int32_t) * 9 * n_tri), *wm = malloc(sizeof(int32_t) * 3 * n_tri);
+        uint32_t first[3];
+        for (int k = 0; k < 3; ++k) {
+            first[k] = (uint32_t)k * n_tri;
+            for (uint32_t t = 0; t < n_tri; ++t) {
+                for (int j = 0; j < 3; ++j)
+                    o_transform_points(tr[k], vtx + 3 * (size_t)idx[3 * t + j], 1, wv + 9 * ((size_t)first[k] + t) + 3 * j);
+                wm[first[k] + t] = mat_ids[t];
+            }
+        }
+        for (uint32_t i = 0; i < 9 * n_tri; ++i) wi[i] = (int32_t)i;
+        memset(film, 0, sizeof(float) * 4u * W * H);
+        for (uint32_t flags = 0; flags < 4; ++flags) {
+            P.flags = flags;
+            cam.mode = (flags & OS_FLAG_DEPTH_GREY) ? 0u : 1u;
+            const uint64_t r = os_render_two_level(top, &mesh, inst, first, wv, wi, mats, wm, &cam, &P,
+                                                   0, 0, W, H, film, nthreads, 3 * n_tri);
+            CHECK(r >= (uint64_t)W * H);
+        }
+        free(wm); free(wi); free(wv);
+    }
+
     free(film); free(img); free(rgba); free(any); free(h1); free(h0); free(rays);
     free(nodes2); free(leaf2); free(nodes); free(leaf); free(mat_ids); free(idx); free(vtx);
 }
