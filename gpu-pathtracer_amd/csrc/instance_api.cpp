@@ -8,6 +8,7 @@
 // the instances' world boxes (pt_instance_bounds).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -146,16 +147,37 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             if (wide.max_depth > wide_depth) wide_depth = wide.max_depth;
         }
 
-        // Instances, and one world-space shading record per instanced triangle.
+        // Instances.  Their world-space shading records are written on the GPU below; the host
+        // only transforms the emissive triangles, for the light list.
         uint64_t total_tris = 0;
+        uint32_t max_mesh_tris = 0;
         for (uint32_t i = 0; i < n_instances; ++i) total_tris += meshes[instances[i].mesh].n_triangles;
         if (total_tris > 0x7fffffffull)
             return fail(PT_ERR_UNSUPPORTED, "pt_scene_create_instanced: more than 2^31 instanced triangles");
+        std::vector<int32_t> mesh_mids;                       // per mesh triangle, meshes back to back
+        std::vector<std::vector<int32_t>> used_ids(n_meshes); // distinct material ids of each mesh
+        bool any_ids = false;
+        for (uint32_t m = 0; m < n_meshes; ++m) any_ids = any_ids || meshes[m].material_ids != nullptr;
+        for (uint32_t m = 0; m < n_meshes; ++m) {
+            const pt_mesh_desc &d = meshes[m];
+            if (d.n_triangles > max_mesh_tris) max_mesh_tris = d.n_triangles;
+            if (d.material_ids) {
+                mesh_mids.insert(mesh_mids.end(), d.material_ids, d.material_ids + d.n_triangles);
+                std::vector<int32_t> u(d.material_ids, d.material_ids + d.n_triangles);
+                std::sort(u.begin(), u.end());
+                u.erase(std::unique(u.begin(), u.end()), u.end());
+                used_ids[m] = std::move(u);
+            } else {
+                if (any_ids) mesh_mids.insert(mesh_mids.end(), d.n_triangles, 0);
+                used_ids[m] = {0};
+            }
+        }
         std::vector<DeviceInstance> dinst(n_instances);
-        std::vector<TriRecord> stris((size_t)total_tris);
-        std::vector<int32_t> mids((size_t)total_tris);
-        std::vector<float> flat_vtx(9 * (size_t)total_tris);   // for the light list only
-        std::vector<int32_t> flat_idx(3 * (size_t)total_tris);
+        std::vector<int32_t> moffs(n_instances);
+        std::vector<float> fwd(12 * (size_t)n_instances);
+        std::vector<float> light_vtx;      // world-space vertices of the emissive triangles
+        std::vector<int32_t> light_ids;    // their indices among all instanced triangles
+        std::vector<int32_t> light_mids;
         uint32_t first = 0;
         for (uint32_t i = 0; i < n_instances; ++i) {
             const pt_instance &in = instances[i];
@@ -172,37 +194,46 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             di.n_tri = d.n_triangles;
             di.first_tri = first;
             di._pad = 0;
-            for (uint32_t t = 0; t < d.n_triangles; ++t) {
-                const int64_t mid = (int64_t)(d.material_ids ? d.material_ids[t] : 0) + in.material_offset;
+            moffs[i] = in.material_offset;
+            std::memcpy(&fwd[12 * (size_t)i], in.object_to_world, sizeof(float) * 12);
+            bool emissive = false;
+            for (int32_t id : used_ids[in.mesh]) {
+                const int64_t mid = (int64_t)id + in.material_offset;
                 if (mid < 0 || mid >= (int64_t)mats.size())
                     return fail(PT_ERR_INVALID, "pt_scene_create_instanced: instance " +
-                                                    std::to_string(i) + ", triangle " + std::to_string(t) +
-                                                    ": material " + std::to_string(mid) + " out of range");
-                float w[3][3];
-                for (int j = 0; j < 3; ++j)
-                    transform_point(in.object_to_world,
-                                    d.vertices + 3 * (size_t)d.indices[3 * (size_t)t + j], w[j]);
-                const size_t g = (size_t)first + t;
-                TriRecord &r = stris[g];
-                r.v0[0] = w[0][0]; r.v0[1] = w[0][1]; r.v0[2] = w[0][2];
-                r.v1x = w[1][0]; r.v1yz[0] = w[1][1]; r.v1yz[1] = w[1][2];
-                r.v2xy[0] = w[2][0]; r.v2xy[1] = w[2][1]; r.v2z = w[2][2];
-                r.primid = (int32_t)mid;                  // the shading copy carries the material id
-                r.pad[0] = r.pad[1] = 0;
-                mids[g] = (int32_t)mid;
-                for (int j = 0; j < 3; ++j) {
-                    std::memcpy(&flat_vtx[9 * g + 3 * (size_t)j], w[j], 12);
-                    flat_idx[3 * g + (size_t)j] = (int32_t)(3 * g + (size_t)j);
+                                                    std::to_string(i) + ": material " +
+                                                    std::to_string(mid) + " out of range");
+                const pt_material &pm = mats[(size_t)mid];
+                emissive = emissive || (pm.ke[0] + pm.ke[1]) + pm.ke[2] > 0.0f;
+            }
+            if (emissive) {
+                for (uint32_t t = 0; t < d.n_triangles; ++t) {
+                    const int32_t mid = (d.material_ids ? d.material_ids[t] : 0) + in.material_offset;
+                    const pt_material &pm = mats[(size_t)mid];
+                    if (!((pm.ke[0] + pm.ke[1]) + pm.ke[2] > 0.0f)) continue;
+                    for (int j = 0; j < 3; ++j) {
+                        float w[3];
+                        transform_point(in.object_to_world,
+                                        d.vertices + 3 * (size_t)d.indices[3 * (size_t)t + j], w);
+                        light_vtx.insert(light_vtx.end(), w, w + 3);
+                    }
+                    light_ids.push_back((int32_t)(first + t));
+                    light_mids.push_back(mid);
                 }
             }
             first += d.n_triangles;
         }
+        // Same list as a single-level scene of all instanced triangles would get: the
+        // non-emissive ones contribute nothing to the running area sum.
         std::vector<int32_t> light_tri;
         std::vector<float> light_cdf;
-        build_light_list(flat_vtx.data(), flat_idx.data(), (uint32_t)total_tris, mats.data(),
-                         mids.data(), light_tri, light_cdf);
-        flat_vtx = std::vector<float>();
-        flat_idx = std::vector<int32_t>();
+        {
+            std::vector<int32_t> seq(light_vtx.size() / 3);
+            for (size_t k = 0; k < seq.size(); ++k) seq[k] = (int32_t)k;
+            build_light_list(light_vtx.data(), seq.data(), (uint32_t)light_ids.size(), mats.data(),
+                             light_mids.data(), light_tri, light_cdf);
+            for (int32_t &t : light_tri) t = light_ids[(size_t)t];
+        }
 
         auto sc = std::make_unique<pt_scene>();
         sc->ctx = ctx;
@@ -226,8 +257,19 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
         d.idx = (const int32_t *)upload(idx_all.data(), sizeof(int32_t) * idx_all.size());
         d.wnodes = (const float4 *)upload(wnodes_all.data(), sizeof(WideNode) * wnodes_all.size());
         d.wtris = (const float4 *)upload(wtris_all.data(), sizeof(TriRecord) * wtris_all.size());
-        d.stris = (const float4 *)upload(stris.data(), sizeof(TriRecord) * stris.size());
-        d.mat_ids = (const int32_t *)upload(mids.data(), sizeof(int32_t) * mids.size());
+        void *d_stris = nullptr;
+        {
+            const hipError_t err = hipMalloc(&d_stris, sizeof(TriRecord) * (size_t)total_tris);
+            if (err != hipSuccess) {
+                sc->release();
+                return hip_fail(err, "pt_scene_create_instanced: shading records");
+            }
+            sc->allocs.push_back(d_stris);
+        }
+        d.stris = (const float4 *)d_stris;
+        // per mesh triangle here (the shading records carry the per-instance ids)
+        d.mat_ids = mesh_mids.empty() ? nullptr
+                                      : (const int32_t *)upload(mesh_mids.data(), sizeof(int32_t) * mesh_mids.size());
         d.materials = (const pt_material *)upload(mats.data(), sizeof(pt_material) * mats.size());
         d.light_tri = nullptr;
         d.light_cdf = nullptr;
@@ -247,6 +289,30 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
         d.instances = (const DeviceInstance *)upload(dinst.data(), sizeof(DeviceInstance) * dinst.size());
         d.n_tlas_nodes = n_top_nodes;
         d.n_instances = n_instances;
+        {
+            // transforms and offsets are only needed to write the shading records
+            void *d_fwd = nullptr, *d_moff = nullptr;
+            hipError_t err = hipMalloc(&d_fwd, sizeof(float) * fwd.size());
+            if (err == hipSuccess) err = hipMalloc(&d_moff, sizeof(int32_t) * moffs.size());
+            if (err == hipSuccess)
+                err = hipMemcpy(d_fwd, fwd.data(), sizeof(float) * fwd.size(), hipMemcpyHostToDevice);
+            if (err == hipSuccess)
+                err = hipMemcpy(d_moff, moffs.data(), sizeof(int32_t) * moffs.size(), hipMemcpyHostToDevice);
+            if (err == hipSuccess) err = hipDeviceSynchronize();   // uploads went through the null stream
+            if (err == hipSuccess) {
+                launch_instance_shading_records(ctx->stream, d, (const float4 *)d_fwd, d.mat_ids,
+                                                (const int32_t *)d_moff, max_mesh_tris,
+                                                (float4 *)d_stris);
+                err = hipGetLastError();
+            }
+            if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+            if (d_fwd) (void)hipFree(d_fwd);
+            if (d_moff) (void)hipFree(d_moff);
+            if (err != hipSuccess) {
+                sc->release();
+                return hip_fail(err, "pt_scene_create_instanced: shading records");
+            }
+        }
         *out = sc.release();
         return PT_OK;
     } catch (const std::bad_alloc &) {

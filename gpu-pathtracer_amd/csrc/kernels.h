@@ -86,6 +86,14 @@ void launch_trace_two_level(hipStream_t st, const DeviceScene &s, const pt_ray *
                             uint64_t n, bool fixup, bool exact, DeviceTraceCounters *counters,
                             bool count_work);
 
+// Fills s.stris (one world-space record per instanced triangle) from the object-space meshes:
+// object_to_world holds 3 float4 rows per instance, mesh_mat_ids one id per mesh triangle in
+// the order of s.idx (or null), material_offset one value per instance.
+void launch_instance_shading_records(hipStream_t st, const DeviceScene &s,
+                                     const float4 *object_to_world, const int32_t *mesh_mat_ids,
+                                     const int32_t *material_offset, uint32_t max_mesh_tris,
+                                     float4 *stris);
+
 // Workgroups of `block` threads a persistent kernel may launch and still have them all
 // resident: compute units x min(cap, what the occupancy query admits).
 unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg, int *cache);
