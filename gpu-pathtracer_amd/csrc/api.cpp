@@ -608,7 +608,7 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
             return fail(PT_ERR_UNSUPPORTED,
                         "pt_trace_closest: PT_TRACE_MOLLER_TRUMBORE is not available on two-level scenes");
         launch_trace_two_level(st, scene->dev, rays_dev, hits_dev, n, fixup, exact, ctx->counters,
-                               count);
+                               count, ctx->extend_config());
     } else if (exact) {
         launch_trace_skiplink(st, scene->dev, rays_dev, hits_dev, n, mt,
                               count ? ctx->counters : nullptr);

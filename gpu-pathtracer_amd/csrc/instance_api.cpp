@@ -130,8 +130,19 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
                                                     " outside the vertex buffer");
             WideBvh wide;
             build_wide_layout(tree, d.vertices, d.n_vertices, d.indices, d.n_triangles, wide);
-            if (wide.nodes.size() > (1u << 26) || wide.tris.size() > 89000000u)
-                return fail(PT_ERR_UNSUPPORTED, tag + "too large for 32-bit record offsets");
+            if (wnodes_all.size() + wide.nodes.size() > (1u << 26) ||
+                wtris_all.size() + wide.tris.size() > 89000000u)
+                return fail(PT_ERR_UNSUPPORTED,
+                            "pt_scene_create_instanced: meshes too large together for 32-bit record offsets");
+            // child indices become scene-wide: an inner child is the index of a two-child node,
+            // a leaf child the complement of its record's position in 16-byte units
+            {
+                const int32_t node_base = (int32_t)wnodes_all.size();
+                const int32_t tri_base = 3 * (int32_t)wtris_all.size();
+                for (WideNode &w : wide.nodes)
+                    for (int c = 0; c < 2; ++c)
+                        w.child[c] = w.child[c] >= 0 ? w.child[c] + node_base : ~(~w.child[c] + tri_base);
+            }
             if (nodes_all.size() + d.n_nodes > 0x7fffffffull ||
                 vtx_all.size() / 3 + d.n_vertices > 0x7fffffffull ||
                 wtris_all.size() + wide.tris.size() > 0x7fffffffull)
@@ -286,6 +297,11 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
         d.link_enc = link_encoding;
         d.wide_depth = wide_depth;
         d.tlas = (const float4 *)upload(top_nodes, sizeof(pt_bbox) * (size_t)n_top_nodes);
+        {
+            std::vector<WideNode> wtop;
+            build_wide_top(top, wtop);
+            d.wtop = (const float4 *)upload(wtop.data(), sizeof(WideNode) * wtop.size());
+        }
         d.instances = (const DeviceInstance *)upload(dinst.data(), sizeof(DeviceInstance) * dinst.size());
         d.n_tlas_nodes = n_top_nodes;
         d.n_instances = n_instances;

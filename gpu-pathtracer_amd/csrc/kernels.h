@@ -47,6 +47,7 @@ struct DeviceScene {
     // arrays above then hold every mesh back to back, in object space, except stris, which
     // holds one world-space record per instanced triangle.
     const float4 *tlas;
+    const float4 *wtop;    // the same top-level tree as two-child nodes; leaf child = ~instance
     const DeviceInstance *instances;
     uint32_t n_tlas_nodes, n_instances;
 };
@@ -84,7 +85,7 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
 // counters must be non-null (its tie_count is always written).
 void launch_trace_two_level(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                             uint64_t n, bool fixup, bool exact, DeviceTraceCounters *counters,
-                            bool count_work);
+                            bool count_work, const ExtendConfig &cfg);
 
 // Fills s.stris (one world-space record per instanced triangle) from the object-space meshes:
 // object_to_world holds 3 float4 rows per instance, mesh_mat_ids one id per mesh triangle in

@@ -131,7 +131,7 @@ __device__ __forceinline__ void traverse_ordered(const DeviceScene &s, const flo
                                                  const float4 rd, int32_t *stack,
                                                  int32_t &primid, float &b0, float &b1, float &b2,
                                                  float &tbest, bool &tie, unsigned long long &nb,
-                                                 unsigned long long &nt) {
+                                                 unsigned long long &nt, int32_t root = 0) {
     const RayPre r = precompute_ray(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
     const float tmax = ro.w;
     b0 = 0.f; b1 = 0.f; b2 = 0.f;
@@ -142,7 +142,7 @@ __device__ __forceinline__ void traverse_ordered(const DeviceScene &s, const flo
     tie = false;
 
     int sp = 0;
-    int32_t cur = 0;             // >= 0: two-child node, < 0: a triangle record (see wide_tri)
+    int32_t cur = root;          // >= 0: two-child node, < 0: a triangle record (see wide_tri)
     // Non-finite rays and zero directions follow whatever the shader's arithmetic makes of
     // them (a NaN distance is "accepted" once and then culls everything): that depends on
     // the visiting order, so they are left to the fixed-order traversal.
@@ -226,7 +226,7 @@ struct OrderedState {
 };
 
 __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro, const float4 rd,
-                                              int32_t *stack) {
+                                              int32_t *stack, int32_t root = 0, int base = 0) {
     st.r = precompute_ray(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
     st.tmax = ro.w;
     st.b0 = 0.f; st.b1 = 0.f; st.b2 = 0.f;
@@ -235,9 +235,9 @@ __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro,
     st.second = INFINITY;
     st.primid = -1;
     st.tie = false;
-    stack[0] = kSentinel;          // bottom of the stack: popping it ends the ray
-    st.sp = 1;
-    st.cur = 0;
+    stack[base * kTraceBlock] = kSentinel;   // bottom of the stack: popping it ends the ray
+    st.sp = base + 1;
+    st.cur = root;
     const float chk = ((ro.x + ro.y) + (ro.z + rd.x)) + (rd.y + rd.z);
     if (!(fabsf(chk) < INFINITY) || !(st.tmax == st.tmax) ||
         (rd.x == 0.f && rd.y == 0.f && rd.z == 0.f)) {
@@ -251,7 +251,8 @@ __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro,
 // slots of the ray, which the Moller-Trumbore test has no use for, carry the direction.
 // exact: leave the ray to the skip-link walk (see occluded_wide for when that is needed).
 __device__ __forceinline__ void any_begin(OrderedState &st, const float4 ro, const float4 rd,
-                                          int32_t *stack, bool exact) {
+                                          int32_t *stack, bool exact, int32_t root = 0,
+                                          int base = 0) {
     st.r.ox = ro.x; st.r.oy = ro.y; st.r.oz = ro.z;
     st.r.ix = 1.0f / rd.x; st.r.iy = 1.0f / rd.y; st.r.iz = 1.0f / rd.z;
     st.r.sx = rd.x; st.r.sy = rd.y; st.r.sz = rd.z;
@@ -263,9 +264,9 @@ __device__ __forceinline__ void any_begin(OrderedState &st, const float4 ro, con
     st.b0 = 0.f; st.b1 = 0.f; st.b2 = 0.f;
     st.primid = -1;                // >= 0 once an occluder has been found
     st.tie = false;
-    stack[0] = kSentinel;
-    st.sp = 1;
-    st.cur = 0;
+    stack[base * kTraceBlock] = kSentinel;
+    st.sp = base + 1;
+    st.cur = root;
     const float chk = ((ro.x + ro.y) + (ro.z + rd.x)) + (rd.y + rd.z);
     if (exact || !(fabsf(chk) < INFINITY) || !(ro.w == ro.w) ||
         (rd.x == 0.f && rd.y == 0.f && rd.z == 0.f)) {
@@ -379,9 +380,9 @@ __device__ __forceinline__ bool closest_hit(const DeviceScene &s, const float4 r
                                             int32_t *stack, bool fixup, int32_t &shapeid,
                                             int32_t &primid, float &b0, float &b1, float &b2,
                                             float &t, unsigned long long &nb,
-                                            unsigned long long &nt) {
+                                            unsigned long long &nt, int32_t root = 0) {
     bool tie;
-    traverse_ordered<COUNT>(s, ro, rd, stack, primid, b0, b1, b2, t, tie, nb, nt);
+    traverse_ordered<COUNT>(s, ro, rd, stack, primid, b0, b1, b2, t, tie, nb, nt, root);
     shapeid = primid >= 0 ? 0 : -1;
     if (tie && fixup) {
         unsigned long long xb = 0, xt = 0;
@@ -440,7 +441,7 @@ __device__ __forceinline__ bool occluded_skiplink(const DeviceScene &s, const fl
 // take the skip-link walk.  Not for single-triangle scenes: their filler record is only
 // safe under the watertight test.
 __device__ __forceinline__ bool occluded_wide(const DeviceScene &s, const float4 ro,
-                                              const float4 rd, int32_t *stack) {
+                                              const float4 rd, int32_t *stack, int32_t root = 0) {
     const float chk = ((ro.x + ro.y) + (ro.z + rd.x)) + (rd.y + rd.z);
     if (!(fabsf(chk) < INFINITY) || !(ro.w == ro.w) ||
         (rd.x == 0.f && rd.y == 0.f && rd.z == 0.f))
@@ -451,7 +452,7 @@ __device__ __forceinline__ bool occluded_wide(const DeviceScene &s, const float4
     r.sx = r.sy = r.sz = 0.f;
     r.axis = 2;
     int sp = 0;
-    int32_t cur = 0;
+    int32_t cur = root;
     for (;;) {
         if (cur >= 0) {
             const float4 *np = wide_node(s, cur);
@@ -498,17 +499,19 @@ __device__ __forceinline__ bool occluded_wide(const DeviceScene &s, const float4
 // with closest_hit / occluded_wide, i.e. with the reference's per-mesh result, so the whole
 // query equals the fixed-order walk of both levels.
 
-// One instance's mesh as a scene of its own; `ray` goes to its object space.
+// One instance's mesh as a scene of its own; `ray` goes to its object space.  The two-child
+// nodes and triangle records of all meshes share one index space (a mesh's child indices are
+// stored scene-wide), so only the arrays of the fixed-order walk are rebased; root receives
+// the mesh's first two-child node.
 __device__ __forceinline__ DeviceScene enter_instance(const DeviceScene &s, int32_t instance,
-                                                      float4 &ro, float4 &rd) {
+                                                      float4 &ro, float4 &rd, int32_t &root) {
     const float4 *ip = reinterpret_cast<const float4 *>(s.instances + instance);
     const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
     const uint4 o0 = reinterpret_cast<const uint4 *>(ip)[3];
     const uint4 o1 = reinterpret_cast<const uint4 *>(ip)[4];
     DeviceScene m = s;
     m.nodes = s.nodes + 2 * (size_t)o0.x;
-    m.wnodes = s.wnodes + 4 * (size_t)o0.y;
-    m.wtris = s.wtris + 3 * (size_t)o0.z;
+    root = (int32_t)o0.y;
     m.vtx = s.vtx + 3 * (size_t)o0.w;
     m.idx = s.idx + 3 * (size_t)o1.x;
     m.n_tri = o1.y;
@@ -555,7 +558,8 @@ __device__ __forceinline__ bool closest_hit_two_level(const DeviceScene &s, cons
             const int32_t payload = decode_link(lo.w, s.link_enc);
             if (payload != -1) {
                 float4 oo = ro, od = rd;
-                const DeviceScene m = enter_instance(s, payload, oo, od);
+                int32_t root;
+                const DeviceScene m = enter_instance(s, payload, oo, od, root);
                 oo.w = t;
                 int32_t sid, pid;
                 float c0, c1, c2, ct;
@@ -563,7 +567,7 @@ __device__ __forceinline__ bool closest_hit_two_level(const DeviceScene &s, cons
                     traverse_skiplink<false, COUNT>(m, oo, od, sid, pid, c0, c1, c2, ct, nb, nt);
                 else
                     tie |= closest_hit<COUNT>(m, oo, od, stack, fixup, sid, pid, c0, c1, c2, ct, nb,
-                                              nt);
+                                              nt, root);
                 if (pid >= 0) {
                     shapeid = payload; primid = pid;
                     b0 = c0; b1 = c1; b2 = c2; t = ct;
@@ -593,9 +597,10 @@ __device__ __forceinline__ bool occluded_two_level(const DeviceScene &s, const f
             const int32_t payload = decode_link(lo.w, s.link_enc);
             if (payload != -1) {
                 float4 oo = ro, od = rd;
-                const DeviceScene m = enter_instance(s, payload, oo, od);
+                int32_t root;
+                const DeviceScene m = enter_instance(s, payload, oo, od, root);
                 const bool occ = (exact || m.n_tri < 2) ? occluded_skiplink(m, oo, od)
-                                                        : occluded_wide(m, oo, od, stack);
+                                                        : occluded_wide(m, oo, od, stack, root);
                 if (occ) return true;
                 idx = link;
             } else {
@@ -704,6 +709,207 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
             continue;                                           // tail positions past the queue end
         }
         ordered_advance<COUNT, ANY>(s, st, stack, pos < stream_len ? 64 - refill : 0, leaf_lanes, nb, nt);
+    }
+    if (!ANY && n_ties) atomicAdd(tie_count, n_ties);
+    if (COUNT) {
+        nb = wave_sum(nb);
+        nt = wave_sum(nt);
+        if (lane == 0) {
+            atomicAdd(&work->box_tests, nb);
+            atomicAdd(&work->tri_tests, nt);
+        }
+    }
+}
+
+// The same persistent loop for two-level scenes.  A lane owns one ray; each instance it
+// reaches is one run of the voted state machine above on the object-space ray.  Lanes whose
+// run has ended are serviced together -- result merged, top-level walk resumed up to the next
+// instance or the end of the ray, idle lanes refilled -- once `refill` of them have gathered
+// (fewer when few lanes are busy), so the voted steps keep most lanes.
+//
+// The top level is walked nearer child first over its own two-child nodes (s.wtop; a leaf
+// child is the complement of an instance index), on the bottom entries of the lane's stack;
+// the mesh search runs above them.  The argument that makes the ordered single-level
+// traversal return the fixed-order result carries over one level up: every mesh is searched
+// with the culling distance (nearest hit widened by the tie window), so a second candidate --
+// in another instance or in the same mesh -- within the window of the nearest one is seen,
+// and such a ray (also one that is non-finite or overflows the stack) is traced again by its
+// lane with closest_hit_two_level, i.e. in the fixed order of both levels.
+//
+// Every service moves a lane's top-level walk forward or retires its ray, and every wave's
+// stream is finite: the grid drains.
+template <bool COUNT, bool ANY, class Sink>
+__device__ __forceinline__ void persistent_traverse_two_level(
+    const DeviceScene &s, const pt_ray *rays, uint32_t n, bool fixup, int refill, int leaf_lanes,
+    int32_t *stack, unsigned int *tie_count, DeviceTraceCounters *work, Sink sink) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * (kTraceBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (kTraceBlock / 64);
+    const uint32_t n_chunks = (n + 63u) >> 6;
+    const uint32_t owned = wave < n_chunks ? (n_chunks - wave + n_waves - 1) / n_waves : 0;
+    const uint32_t stream_len = owned << 6;
+    uint32_t pos = 0;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    constexpr int kTopStack = kTraceStack / 2;   // entries the top-level walk may hold
+    uint32_t my_ray = kNone;
+    OrderedState st;
+    st.cur = kSentinel;
+    st.tie = false;
+    st.primid = -1;
+    st.second = INFINITY;
+    st.tbest = 0.f;
+    st.tmax = 0.f;
+    int32_t top_cur = kSentinel;   // top-level item to visit next (kSentinel: pop one)
+    int top_sp = 0;                // top-level entries on the stack
+    int32_t cur_inst = -1;         // instance whose mesh is being searched
+    bool ray_tie = false;          // leave this ray to the fixed-order walk
+    int32_t best_shape = -1, best_prim = -1;
+    float best_b0 = 0.f, best_b1 = 0.f, best_b2 = 0.f, best_t = 0.f;
+    float second = INFINITY, bound = 0.f;
+    unsigned long long nb = 0, nt = 0;
+    unsigned int n_ties = 0;
+    for (;;) {
+        if (my_ray != kNone && st.cur == kSentinel) {
+            const float4 ro = reinterpret_cast<const float4 *>(rays + my_ray)[0];
+            const float4 rd = reinterpret_cast<const float4 *>(rays + my_ray)[1];
+            bool done = false;
+            if (cur_inst >= 0) {                                // merge the finished mesh search
+                if constexpr (ANY) {
+                    bool occ = st.primid >= 0;
+                    if (st.tie) {
+                        float4 oo = ro, od = rd;
+                        int32_t root;
+                        const DeviceScene m = enter_instance(s, cur_inst, oo, od, root);
+                        occ = occluded_skiplink(m, oo, od);
+                    }
+                    done = occ;
+                    best_prim = occ ? 0 : -1;
+                } else {
+                    ray_tie |= ordered_is_tie(st);
+                    const int32_t pid = st.primid;
+                    const float ct = st.tbest;
+                    if (pid >= 0) {
+                        if (best_prim < 0 || ct < best_t) {
+                            if (best_prim >= 0) second = fminf(second, best_t);
+                            best_shape = cur_inst; best_prim = pid;
+                            best_b0 = st.b0; best_b1 = st.b1; best_b2 = st.b2; best_t = ct;
+                            bound = fminf(ct + ct * PT_TIE_WINDOW, ro.w);
+                        } else if (cur_inst != best_shape || pid != best_prim) {
+                            second = fminf(second, ct);
+                        }   // else: the same instance reached through another top-level leaf
+                    }
+                }
+                cur_inst = -1;
+            }
+            if (!done && !ray_tie) {                            // on to the next instance
+                const RayPre r = top_level_ray(ro, rd);
+                const float lim = ANY ? ro.w : bound;
+                for (;;) {
+                    if (top_cur == kSentinel) {
+                        if (top_sp == 0) break;
+                        --top_sp;
+                        top_cur = stack[top_sp * kTraceBlock];
+                    }
+                    if (top_cur >= 0) {
+                        const float4 *np = reinterpret_cast<const float4 *>(
+                            reinterpret_cast<const char *>(s.wtop) + ((uint32_t)top_cur << 6));
+                        const float4 a = np[0], b = np[1], c = np[2];
+                        const int4 ch = reinterpret_cast<const int4 *>(np)[3];
+                        if (COUNT) nb += 2;
+                        float ta, tb;
+                        const bool ha = intersect_box(r, a.x, a.y, a.z, a.w, c.x, c.y, lim, ta);
+                        const bool hb = intersect_box(r, b.x, b.y, b.z, b.w, c.z, c.w, lim, tb);
+                        if (ha && hb) {
+                            if (top_sp >= kTopStack) {
+                                ray_tie = true;
+                                break;
+                            }
+                            const bool swap = tb < ta;
+                            stack[top_sp * kTraceBlock] = swap ? ch.x : ch.y;
+                            ++top_sp;
+                            top_cur = swap ? ch.y : ch.x;
+                        } else if (ha || hb) {
+                            top_cur = ha ? ch.x : ch.y;
+                        } else {
+                            top_cur = kSentinel;
+                        }
+                    } else {
+                        cur_inst = ~top_cur;
+                        top_cur = kSentinel;
+                        float4 oo = ro, od = rd;
+                        int32_t root;
+                        const DeviceScene m = enter_instance(s, cur_inst, oo, od, root);
+                        if constexpr (ANY) {
+                            any_begin(st, oo, od, stack, m.n_tri < 2, root, top_sp);
+                        } else {
+                            oo.w = bound;
+                            ordered_begin(st, oo, od, stack, root, top_sp);
+                        }
+                        break;
+                    }
+                }
+            }
+            if (!done) done = cur_inst < 0;                     // no further instance: the ray ends
+            if (done) {
+                if constexpr (ANY) {
+                    bool occ = best_prim >= 0;
+                    if (ray_tie) occ = occluded_two_level(s, ro, rd, stack, false);
+                    sink(my_ray, occ);
+                } else {
+                    const bool tie = ray_tie || (best_prim >= 0 &&
+                                                 second <= best_t + best_t * PT_TIE_WINDOW);
+                    if (tie) {
+                        ++n_ties;
+                        if (fixup) {
+                            unsigned long long xb = 0, xt = 0;
+                            closest_hit_two_level<false>(s, ro, rd, stack, true, false, best_shape,
+                                                         best_prim, best_b0, best_b1, best_b2,
+                                                         best_t, xb, xt);
+                        }
+                    }
+                    sink(my_ray, best_shape, best_prim, best_b0, best_b1, best_b2, best_t);
+                }
+                my_ray = kNone;
+                st.cur = kSentinel;
+                cur_inst = -1;
+            }
+        }
+        const bool idle = my_ray == kNone;
+        const unsigned long long m = __ballot(idle);
+        if (pos < stream_len && m) {                            // hand idle lanes their next rays
+            const uint32_t p = pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (idle && p < stream_len) {
+                const uint32_t idx = (((p >> 6) * n_waves + wave) << 6) + (p & 63u);
+                if (idx < n) {
+                    const float4 ro = reinterpret_cast<const float4 *>(rays + idx)[0];
+                    const float4 rd = reinterpret_cast<const float4 *>(rays + idx)[1];
+                    my_ray = idx;
+                    top_cur = 0;
+                    top_sp = 0;
+                    cur_inst = -1;
+                    best_shape = -1; best_prim = -1;
+                    best_b0 = 0.f; best_b1 = 0.f; best_b2 = 0.f;
+                    best_t = ro.w;
+                    bound = ro.w;
+                    second = INFINITY;
+                    st.cur = kSentinel;
+                    // non-finite rays and zero directions: whatever the fixed-order arithmetic
+                    // makes of them (see traverse_ordered)
+                    const float chk = ((ro.x + ro.y) + (ro.z + rd.x)) + (rd.y + rd.z);
+                    ray_tie = !(fabsf(chk) < INFINITY) || !(ro.w == ro.w) ||
+                              (rd.x == 0.f && rd.y == 0.f && rd.z == 0.f);
+                }
+            }
+            pos += (uint32_t)__popcll(m);
+            continue;                                           // they start their top-level walk above
+        }
+        const int active = (int)__popcll(__ballot(st.cur != kSentinel));
+        if (active == 0) {
+            if (__ballot(my_ray != kNone) == 0ull) break;       // stream read and every ray retired
+            continue;                                           // lanes waiting for service only
+        }
+        const int batch = min(refill, max(1, active >> 1));
+        ordered_advance<COUNT, ANY>(s, st, stack, active - batch, leaf_lanes, nb, nt);
     }
     if (!ANY && n_ties) atomicAdd(tie_count, n_ties);
     if (COUNT) {

@@ -123,6 +123,16 @@ __global__ __launch_bounds__(kBlock) void k_pt_extend_two_level(DeviceScene s, c
     }
 }
 
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_two_level_persistent(
+    DeviceScene s, const pt_ray *rays, pt_hit *hits, const unsigned int *count,
+    unsigned int *tie_count, DeviceTraceCounters *work, int refill, int leaf_lanes) {
+    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
+    persistent_traverse_two_level<COUNT, false>(s, rays, *count, true, refill, leaf_lanes,
+                                                s_stack + threadIdx.x, tie_count, work,
+                                                HitSink{hits});
+}
+
 // extend, persistent form: the grid is sized to the machine, not to the queue.  Queue
 // chunks of 64 rays are dealt round-robin to the waves (chunk c belongs to wave c % n_waves:
 // static, so no work-distribution atomics), and a wave tops its idle lanes up from its own
@@ -271,6 +281,14 @@ __global__ __launch_bounds__(kBlock) void k_pt_occlude_two_level(DeviceScene s, 
     ShadowSink{ws.shadow_carry, ws.radiance}((uint32_t)i, occ);
 }
 
+__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_two_level_persistent(
+    DeviceScene s, RenderWorkspace ws, const unsigned int *count, int refill, int leaf_lanes) {
+    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
+    persistent_traverse_two_level<false, true>(s, ws.shadow_rays, *count, true, refill, leaf_lanes,
+                                               s_stack + threadIdx.x, nullptr, nullptr,
+                                               ShadowSink{ws.shadow_carry, ws.radiance});
+}
+
 // Persistent waves with lane refill and step voting, as the closest-hit kernel.
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_persistent(
     DeviceScene s, RenderWorkspace ws, const unsigned int *count, int refill, int leaf_lanes) {
@@ -344,6 +362,20 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
                       const unsigned int *count, uint64_t max_rays, unsigned int *tie_count,
                       DeviceTraceCounters *work, const ExtendConfig &cfg) {
     if (!max_rays) return;
+    if (s.tlas && cfg.persistent_blocks > 0) {
+        static int occ2[2] = {0, 0};
+        const void *k = work ? (const void *)k_pt_extend_two_level_persistent<true>
+                             : (const void *)k_pt_extend_two_level_persistent<false>;
+        const unsigned int grid = (unsigned int)std::min<uint64_t>(
+            blocks(max_rays, kBlock), persistent_grid(k, kBlock, cfg, &occ2[work ? 1 : 0]));
+        if (work)
+            hipLaunchKernelGGL(k_pt_extend_two_level_persistent<true>, dim3(grid), dim3(kBlock), 0, st,
+                               s, ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes);
+        else
+            hipLaunchKernelGGL(k_pt_extend_two_level_persistent<false>, dim3(grid), dim3(kBlock), 0, st,
+                               s, ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes);
+        return;
+    }
     if (s.tlas) {
         if (work)
             hipLaunchKernelGGL(k_pt_extend_two_level<true>, dim3(blocks(max_rays, kBlock)),
@@ -388,6 +420,15 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
                        const unsigned int *shadow_count, uint64_t max_rays,
                        const ExtendConfig &cfg) {
     if (!max_rays) return;
+    if (s.tlas && cfg.persistent_blocks > 0) {
+        static int occ2 = 0;
+        const unsigned int grid = (unsigned int)std::min<uint64_t>(
+            blocks(max_rays, kBlock),
+            persistent_grid((const void *)k_pt_occlude_two_level_persistent, kBlock, cfg, &occ2));
+        hipLaunchKernelGGL(k_pt_occlude_two_level_persistent, dim3(grid), dim3(kBlock), 0, st, s, ws,
+                           shadow_count, cfg.refill, cfg.leaf_lanes);
+        return;
+    }
     if (s.tlas) {
         hipLaunchKernelGGL(k_pt_occlude_two_level, dim3(blocks(max_rays, kBlock)), dim3(kBlock), 0,
                            st, s, ws, shadow_count);

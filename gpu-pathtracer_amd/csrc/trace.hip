@@ -146,6 +146,24 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_two_level(DeviceScene s, c
     occluded[i] = occluded_two_level(s, ro, rd, s_stack + threadIdx.x, exact) ? 1 : 0;
 }
 
+// Two-level scenes by persistent waves (see persistent_traverse_two_level).
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_two_level_persistent(
+    DeviceScene s, const pt_ray *rays, pt_hit *hits, uint32_t n, bool fixup, int refill,
+    int leaf_lanes, DeviceTraceCounters *counters) {
+    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
+    persistent_traverse_two_level<COUNT, false>(s, rays, n, fixup, refill, leaf_lanes,
+                                                s_stack + threadIdx.x, &counters->tie_count,
+                                                counters, HitSink{hits});
+}
+__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_two_level_persistent(
+    DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, int refill, int leaf_lanes) {
+    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
+    persistent_traverse_two_level<false, true>(s, rays, n, true, refill, leaf_lanes,
+                                               s_stack + threadIdx.x, nullptr, nullptr,
+                                               OccludedSink{occluded});
+}
+
 // Sort key of a ray: 30-bit Morton code of its origin's cell in a 1024^3 grid over the scene's
 // root box.  Rays that start close together walk the same part of the tree; on scenes much
 // larger than the caches that is worth more than the sort costs.
@@ -214,8 +232,22 @@ void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *r
 
 void launch_trace_two_level(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                             uint64_t n, bool fixup, bool exact, DeviceTraceCounters *counters,
-                            bool count_work) {
+                            bool count_work, const ExtendConfig &cfg) {
     if (n == 0) return;
+    if (!exact && cfg.persistent_blocks > 0) {
+        static int occ[2] = {0, 0};
+        const void *k = count_work ? (const void *)k_trace_two_level_persistent<true>
+                                   : (const void *)k_trace_two_level_persistent<false>;
+        const unsigned int grid = (unsigned int)std::min<uint64_t>(
+            grid_for(n), persistent_grid(k, kBlock, cfg, &occ[count_work ? 1 : 0]));
+        if (count_work)
+            hipLaunchKernelGGL((k_trace_two_level_persistent<true>), dim3(grid), dim3(kBlock), 0, st,
+                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, counters);
+        else
+            hipLaunchKernelGGL((k_trace_two_level_persistent<false>), dim3(grid), dim3(kBlock), 0, st,
+                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, counters);
+        return;
+    }
     if (count_work)
         hipLaunchKernelGGL((k_trace_two_level<true>), dim3(grid_for(n)), dim3(kBlock), 0, st, s,
                            rays, hits, n, fixup, exact, counters);
@@ -229,7 +261,7 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
                           bool count_work, const ExtendConfig &cfg, DeviceBuffer *sort_scratch) {
     if (n == 0) return;
     if (s.tlas) {
-        launch_trace_two_level(st, s, rays, hits, n, fixup, false, counters, count_work);
+        launch_trace_two_level(st, s, rays, hits, n, fixup, false, counters, count_work, cfg);
         return;
     }
     if (cfg.persistent_blocks > 0) {
@@ -278,6 +310,15 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
                       uint64_t n, bool exact_order, const ExtendConfig &cfg) {
     if (n == 0) return;
     if (s.tlas) {
+        if (!exact_order && cfg.persistent_blocks > 0) {
+            static int occ2 = 0;
+            const unsigned int grid = (unsigned int)std::min<uint64_t>(
+                grid_for(n),
+                persistent_grid((const void *)k_trace_any_two_level_persistent, kBlock, cfg, &occ2));
+            hipLaunchKernelGGL(k_trace_any_two_level_persistent, dim3(grid), dim3(kBlock), 0, st, s,
+                               rays, occluded, (uint32_t)n, cfg.refill, cfg.leaf_lanes);
+            return;
+        }
         hipLaunchKernelGGL(k_trace_any_two_level, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays,
                            occluded, n, exact_order);
         return;

@@ -85,6 +85,8 @@ void build_light_list(const float *vtx, const int32_t *idx, uint32_t n_tri,
                       const pt_material *materials, const int32_t *material_ids,
                       std::vector<int32_t> &tri, std::vector<float> &cdf);
 
+void build_wide_top(const BvhTree &t, std::vector<WideNode> &out);
+
 // Two-level scenes (instances.cpp).  m, inv: 3x4, three rows of (linear part | translation).
 bool invert_affine(const float m[12], float inv[12]);           // false: singular or non-finite
 void transform_point(const float m[12], const float p[3], float out[3]);

@@ -232,4 +232,36 @@ void build_wide_layout(const BvhTree &t, const float *vtx, uint32_t n_vtx, const
     }
 }
 
+// Two-child nodes of a top-level tree: children numbered like build_wide_layout's inner nodes,
+// a leaf child is the complement of its payload (an instance index).  A single-leaf tree gets
+// one node naming that leaf twice.
+void build_wide_top(const BvhTree &t, std::vector<WideNode> &out) {
+    const size_t n = t.size();
+    out.assign(t.n_prims > 1 ? t.n_prims - 1 : 1, WideNode{});
+    std::vector<int32_t> slot(n);
+    {
+        int32_t ni = 0;
+        for (size_t i = 0; i < n; ++i) slot[i] = t.right[i] >= 0 ? ni++ : ~t.prim[i];
+    }
+    auto set_child = [&](WideNode &w, int c, size_t node) {
+        const pt_bbox &b = t.bounds[node];
+        float *xy = c == 0 ? w.c0xy : w.c1xy;
+        xy[0] = b.pmin[0]; xy[1] = b.pmax[0]; xy[2] = b.pmin[1]; xy[3] = b.pmax[1];
+        w.cz[2 * c + 0] = b.pmin[2];
+        w.cz[2 * c + 1] = b.pmax[2];
+        w.child[c] = slot[node];
+    };
+    if (n == 1) {
+        set_child(out[0], 0, 0);
+        set_child(out[0], 1, 0);
+        return;
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (t.right[i] >= 0) {
+            WideNode &w = out[(size_t)slot[i]];
+            set_child(w, 0, i + 1);
+            set_child(w, 1, (size_t)t.right[i]);
+        }
+}
+
 } // namespace mipt

@@ -50,6 +50,16 @@ def test_closest_and_any_hits_are_bit_exact(mipt, oracle, gpu_ctx, builder):
             np.testing.assert_array_equal(scene.trace_any(rays), t.any_hit(rays, nthreads=8))
         finally:
             gpu_ctx.set_option("any.exact_order", 0)
+        # one thread per ray instead of persistent waves: same answers
+        gpu_ctx.set_option("extend.persistent", 0)
+        try:
+            assert same_hits(scene.trace_closest(rays), want, nan_equal=True).size == 0
+            np.testing.assert_array_equal(scene.trace_any(rays), t.any_hit(rays, nthreads=8))
+        finally:
+            gpu_ctx.set_option("extend.persistent", 1)
+        # a batch smaller than one wave, and an empty one
+        assert same_hits(scene.trace_closest(rays[:37]), want[:37], nan_equal=True).size == 0
+        assert scene.trace_closest(rays[:0]).shape[0] == 0
         with pytest.raises(mipt.MiptError, match="two-level"):
             scene.trace_closest(rays[:8], flags=mipt.PT_TRACE_MOLLER_TRUMBORE)
         with pytest.raises(mipt.MiptError, match="two-level"):

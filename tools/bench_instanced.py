@@ -1,7 +1,7 @@
 """Closest-hit rate on a two-level scene (one mesh placed many times) beside the same
 triangles flattened into one tree built on the GPU.  Primary rays from a camera over the
 field and their diffuse bounce rays.
-  python tools/bench_instanced.py [n_side=16] [mesh_tris=65536]"""
+  python tools/bench_instanced.py [n_side=16] [mesh_tris=65536] [option=value ...]"""
 import os, sys, json, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "gpu-pathtracer_amd"))
@@ -14,6 +14,9 @@ from mipt import scenes
 n_side = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 mesh_tris = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 ctx = mipt.Context(0)
+for o in sys.argv[3:]:                      # context options, key=value
+    k, _, v = o.partition("=")
+    ctx.set_option(k, int(v))
 st = torch.cuda.Stream(); torch.cuda.set_stream(st); ctx.set_stream(st.cuda_stream)
 
 vtx, idx, mats, mids = scenes.displaced_sphere(mesh_tris, seed=3)
