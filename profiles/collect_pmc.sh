@@ -19,7 +19,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d $out/g$i -o g$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/g$i.log 2>&1
   rc=$?
   echo "group $i ($grp): rc=$rc"
-  if [ $rc -ne 0 ]; then tail -3 $out/g$i.log; fi
+  if [ $rc -ne 0 ]; then tail -3 $out/g$i.log; echo "stopping: nothing more is started on the GPU after a failed pass"; exit $rc; fi
 done
 python3 profiles/summarize_pmc.py $out > $out/summary.txt 2>&1
 cat $out/summary.txt
