@@ -290,12 +290,19 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                                                 int32_t *stack, int min_active, int leaf_lanes,
                                                 unsigned long long &nb, unsigned long long &nt) {
     for (;;) {
-        const bool at_node = st.cur >= 0;
-        const bool at_leaf = (st.cur < 0) & (st.cur != kSentinel);
-        const int n_node = (int)__popcll(__ballot(at_node));
-        const int n_leaf = (int)__popcll(__ballot(at_leaf));
-        if (n_node + n_leaf <= min_active) break;
-        if (n_node != 0 && n_leaf < leaf_lanes) {
+        // Node steps run in a loop of their own: only the position and the stack pointer
+        // change in it, so the rest of the lane's state stays put in its registers.
+        // The vote: 0 node step, 1 triangle step, 2 done (the same value in every lane).
+        auto vote = [&](bool &at_node, bool &at_leaf) {
+            at_node = st.cur >= 0;
+            at_leaf = (st.cur < 0) & (st.cur != kSentinel);
+            const int n_node = (int)__popcll(__ballot(at_node));
+            const int n_leaf = (int)__popcll(__ballot(at_leaf));
+            return (n_node + n_leaf <= min_active) ? 2 : ((n_node != 0 && n_leaf < leaf_lanes) ? 0 : 1);
+        };
+        bool at_node, at_leaf;
+        int mode = vote(at_node, at_leaf);
+        while (mode == 0) {
             if (at_node) {
                 const float4 *np = wide_node(s, st.cur);
                 const float4 a = np[0], b = np[1], c = np[2];
@@ -321,7 +328,10 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                 }
                 st.cur = full ? kSentinel : next;
             }
-        } else if (at_leaf) {
+            mode = vote(at_node, at_leaf);
+        }
+        if (mode == 2) return;
+        if (at_leaf) {
             const float4 *tp = wide_tri(s, st.cur);
             const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
 #ifdef PT_WAVE_ITERS
@@ -644,7 +654,10 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                                                     DeviceTraceCounters *work, Sink sink,
                                                     const uint32_t *perm = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * (kTraceBlock / 64) + (threadIdx.x >> 6);
+    // readfirstlane: the wave index is the same in all 64 lanes, which the compiler cannot see
+    // from threadIdx; with it the stream bookkeeping and the loop control stay scalar
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(blockIdx.x * (kTraceBlock / 64) + (threadIdx.x >> 6)));
     const uint32_t n_waves = gridDim.x * (kTraceBlock / 64);
     const uint32_t n_chunks = (n + 63u) >> 6;
     const uint32_t owned = wave < n_chunks ? (n_chunks - wave + n_waves - 1) / n_waves : 0;
@@ -743,7 +756,10 @@ __device__ __forceinline__ void persistent_traverse_two_level(
     const DeviceScene &s, const pt_ray *rays, uint32_t n, bool fixup, int refill, int leaf_lanes,
     int32_t *stack, unsigned int *tie_count, DeviceTraceCounters *work, Sink sink) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * (kTraceBlock / 64) + (threadIdx.x >> 6);
+    // readfirstlane: the wave index is the same in all 64 lanes, which the compiler cannot see
+    // from threadIdx; with it the stream bookkeeping and the loop control stay scalar
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(blockIdx.x * (kTraceBlock / 64) + (threadIdx.x >> 6)));
     const uint32_t n_waves = gridDim.x * (kTraceBlock / 64);
     const uint32_t n_chunks = (n + 63u) >> 6;
     const uint32_t owned = wave < n_chunks ? (n_chunks - wave + n_waves - 1) / n_waves : 0;
