@@ -101,6 +101,28 @@ def test_render_matches_the_cpu_restatement(mipt, oracle, gpu_ctx, flags):
         scene.close()
 
 
+def test_integer_bit_links(mipt, oracle, gpu_ctx):
+    """All trees in the integer-bit-pattern link encoding (src/bvh/bvh_builder.h:29-33 as
+    documented): same hits as with float-valued links."""
+    sc = tl.scene(n_blob_tris=150, n_blobs=5)
+    t, ref_scene = _build(mipt, oracle, gpu_ctx, sc)
+    opt = mipt.bvh_options(**{"bvh.builder": "sah", "mipt.link_encoding": "int"})
+    meshes = [(mipt.build_bvh(mipt.mesh_leaf_bounds(v, i), opt), v, i, m) for v, i, m in sc["meshes"]]
+    top = mipt.build_bvh(mipt.instance_bounds(meshes, sc["transforms"], sc["mesh_of"]), opt)
+    scene = mipt.Scene.instanced(gpu_ctx, meshes, sc["transforms"], sc["mesh_of"], top,
+                                 materials=tl.materials(mipt), material_offsets=sc["material_offsets"],
+                                 link_encoding=mipt.PT_LINKS_INT_BITS)
+    try:
+        rays = tl.rays_for(20000, 6, mipt.ray_dtype)
+        want = t.closest(rays, nthreads=8)
+        for flags in (mipt.PT_TRACE_DEFAULT, mipt.PT_TRACE_EXACT_ORDER):
+            assert same_hits(scene.trace_closest(rays, flags=flags), want, nan_equal=True).size == 0
+        np.testing.assert_array_equal(scene.trace_any(rays), t.any_hit(rays, nthreads=8))
+    finally:
+        scene.close()
+        ref_scene.close()
+
+
 def test_bad_input_is_rejected(mipt, oracle, gpu_ctx):
     sc = tl.scene(n_blob_tris=40, n_blobs=2)
     opt = mipt.bvh_options()

@@ -1,7 +1,6 @@
 """Host side of the boundary, on the CPU: builder, linearizer, options, OBJ reader.
 The product's skip-link arrays are checked structurally, against the oracle's linearizer on
 the same tree, and functionally (oracle traversal over product nodes == linear scan)."""
-import os
 
 import numpy as np
 import pytest

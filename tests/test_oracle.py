@@ -1,6 +1,5 @@
 """The CPU oracle against the literals the reference text holds, and against itself
 (skip-link traversal == linear scan).  No GPU, no product code."""
-import ctypes as C
 
 import numpy as np
 import pytest
