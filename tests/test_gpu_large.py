@@ -3,6 +3,9 @@ through size-independent properties on everything.
 
 * config 4: San-Miguel-class scene (9.3 M triangles, 18.5 M nodes > 2^24, so the reference's
   float-valued links cannot express it), 3840x2160, one of 8 tile shards, primary + 1 bounce.
+* config 5: Lucy-class closed surface (28 M triangles), tree built on the GPU, 2^22 incoherent
+  secondary rays: both traversal orders, both ray orders, one answer; a sample against the CPU
+  restatement walking the GPU-built tree.
 * config 2: Cornell box 1920x1080, 64 spp, depth 4, Lambertian: the whole frame on the GPU,
   a random subset of pixels recomputed by the CPU restatement.
 """
@@ -63,6 +66,36 @@ def test_san_miguel_class_4k_tile_shard(mipt, oracle, scenes, gpu_ctx, big_scene
         mipt.render(gpu_ctx, sc, cam, p, film)
         np.testing.assert_array_equal(film.read(), 2 * img)
         film.close()
+    finally:
+        sc.close()
+
+
+def test_lucy_class_28m_secondary_rays_gpu_built_tree(mipt, oracle, scenes, gpu_ctx):
+    vtx, idx, _, _ = scenes.displaced_sphere(28_000_000, seed=7)
+    assert idx.shape[0] > 27_000_000
+    sc = mipt.Scene(gpu_ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)   # pt_scene_build
+    try:
+        rays = scenes.surface_rays(vtx, idx, 1 << 22, seed=7).astype(mipt.ray_dtype)
+        got, st = sc.trace_closest(rays, stats=True)      # > 256 MB of traversal data: origin-cell order
+        gpu_ctx.set_option("trace.sort_rays", 0)
+        try:
+            plain = sc.trace_closest(rays)                # queue order
+        finally:
+            gpu_ctx.set_option("trace.sort_rays", -1)
+        assert len(same_hits(got, plain)) == 0
+        sub = np.random.default_rng(3).choice(len(rays), 300_000, replace=False)
+        assert len(same_hits(sc.trace_closest(rays[sub], mipt.PT_TRACE_EXACT_ORDER), got[sub])) == 0
+        assert 0.4 < (got["primid"] >= 0).mean() < 0.95
+        assert got["primid"].max() > 2 ** 24
+        nodes = sc.read_nodes()                           # the tree the GPU built, 56 M nodes
+        assert nodes.shape[0] == 2 * idx.shape[0] - 1
+        pick = sub[:20_000]
+        want = oracle.closest(nodes, vtx, idx, rays[pick], nthreads=16, int_bits=True)
+        assert len(same_hits(got[pick], want)) == 0
+        occ = sc.trace_any(rays[sub])
+        assert ((occ != 0) == (got["primid"][sub] >= 0)).mean() > 0.999   # edge slack of the any-hit test only
+        print(f"28M tris: {st.box_tests / len(rays):.1f} box + {st.tri_tests / len(rays):.1f} tri tests per ray, "
+              f"{st.tie_rays} ties of {len(rays)}")
     finally:
         sc.close()
 
