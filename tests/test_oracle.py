@@ -159,6 +159,54 @@ def test_bvh_equals_linear_scan(oracle, scenes, n_tri, seed, use_sah):
     assert ((a["primid"] >= 0) & (occl == 0)).sum() <= 2
 
 
+def test_hits_agree_with_double_precision_geometry(oracle, scenes):
+    """Independent of the reference's text: the nearest intersection computed by a plain
+    double-precision Moller-Trumbore over all triangles.  Wherever that answer is clear-cut
+    (not within 1e-5 of an edge, no other triangle within 1e-5 of the same distance) the
+    restated watertight traversal must name the same triangle, distance and barycentrics."""
+    from oracle.oracle import ray_dtype
+    vtx, idx, _, _ = scenes.random_soup(1500, seed=9)
+    nodes = oracle.build_bvh(oracle.mesh_leaf_bounds(vtx, idx))
+    rays = random_rays(6000, 77, dtype=ray_dtype)
+    got = oracle.closest(nodes, vtx, idx, rays, nthreads=8)
+    v = vtx.astype(np.float64)[idx]                       # [T,3,3]
+    e1, e2 = v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+    checked = 0
+    for k in range(rays.shape[0]):
+        o, d = rays["o"][k, :3].astype(np.float64), rays["d"][k, :3].astype(np.float64)
+        pv = np.cross(d, e2)
+        det = np.einsum("ij,ij->i", e1, pv)
+        ok = np.abs(det) > 1e-14
+        inv = np.where(ok, 1.0 / np.where(ok, det, 1.0), 0.0)
+        tv = o - v[:, 0]
+        u = np.einsum("ij,ij->i", tv, pv) * inv
+        qv = np.cross(tv, e1)
+        w = np.einsum("j,ij->i", d, qv) * inv
+        t = np.einsum("ij,ij->i", e2, qv) * inv
+        inside = ok & (u >= 0) & (w >= 0) & (u + w <= 1) & (t > 0)
+        if not inside.any():
+            margin = ok & (u > -1e-5) & (w > -1e-5) & (u + w < 1 + 1e-5) & (t > -1e-5)
+            if not margin.any():
+                assert got["primid"][k] == -1
+                checked += 1
+            continue
+        ts = np.where(inside, t, np.inf)
+        best = int(np.argmin(ts))
+        others = np.delete(ts, best)
+        clear = (min(u[best], w[best], 1 - u[best] - w[best]) > 1e-5 and
+                 others.min() > ts[best] * (1 + 1e-5) + 1e-5)
+        near_edge_closer = (ok & (t > 0) & (t < ts[best]) & (u > -1e-5) & (w > -1e-5) & (u + w < 1 + 1e-5)).any()
+        if not clear or near_edge_closer:
+            continue
+        checked += 1
+        assert got["primid"][k] == best
+        b0, b1, b2, tt = got["uvwt"][k]
+        # the watertight test reports (b0, b1, b2) for (v0, v1, v2); u, w weigh v1, v2
+        np.testing.assert_allclose([b1, b2, tt], [u[best], w[best], ts[best]], rtol=2e-4, atol=2e-5)
+        assert abs(b0 + b1 + b2 - 1) < 1e-5
+    assert checked > 4000
+
+
 def test_cornell_primary_hits_vs_linear_scan(oracle, scenes):
     """Config #1 of the baseline: Cornell box, 256x256 pixel-centre primary rays, on the CPU.
     BVH order and index order may disagree only where two triangles are hit at distances

@@ -71,6 +71,10 @@ d /= np.linalg.norm(d, axis=1, keepdims=True)
 b = rays.copy(); b["o"][:, :3] = o; b["d"][:, :3] = d
 d_b = torch.from_numpy(b.view(np.float32).reshape(-1, 8)).cuda()
 out["two_level_bounce_mrays_s"] = rate(two, d_b)
+st = two.trace_closest_device_counted(d_b.data_ptr(), n, d_h.data_ptr())
+out["bounce_boxes_per_ray"] = st.box_tests / n
+out["bounce_triangles_per_ray"] = st.tri_tests / n
+out["bounce_rays_retraced_in_fixed_order"] = st.tie_rays / n
 h2 = d_h.cpu().numpy().view(mipt.hit_dtype).reshape(-1).copy()
 
 if n_side * n_side * mesh_tris <= 80_000_000:
