@@ -19,7 +19,8 @@ struct DeviceBuildResult {
 // Builds, from device-resident vertices and indices of n >= 2 triangles, the skip-link node
 // array (2n-1 nodes, 2 x float4 each), the two-child nodes (n-1, 4 x float4 each) and the
 // triangle records (n, 3 x float4 each) in leaf order, and the shading records (the same
-// vertices with the material id, in the caller's triangle order).  ploc_radius 0: binary
+// vertices with the material id, in the caller's triangle order; skipped if d_stris is null).
+// ploc_radius 0: binary
 // radix tree over the Morton codes; > 0: locally-ordered clustering with that search radius.
 // Blocks until done.
 DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, const int32_t *d_idx,

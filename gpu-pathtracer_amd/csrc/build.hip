@@ -293,10 +293,12 @@ __global__ __launch_bounds__(kB) void k_emit_leaf(EmitArgs a) {
     r[0] = make_float4(v0[0], v0[1], v0[2], v1[0]);
     r[1] = make_float4(v1[1], v1[2], v2[0], v2[1]);
     r[2] = make_float4(v2[2], __int_as_float((int32_t)tri), 0.f, 0.f);
-    float4 *q = a.stris + 3 * (size_t)tri;
-    q[0] = r[0];
-    q[1] = r[1];
-    q[2] = make_float4(v2[2], __int_as_float(a.mat_ids[tri]), 0.f, 0.f);
+    if (a.stris) {               // shading copy (not wanted for a mesh of a two-level scene)
+        float4 *q = a.stris + 3 * (size_t)tri;
+        q[0] = r[0];
+        q[1] = r[1];
+        q[2] = make_float4(v2[2], __int_as_float(a.mat_ids[tri]), 0.f, 0.f);
+    }
 }
 
 // ---- the other tree: parallel locally-ordered clustering (Meister & Bittner 2018) -------------
@@ -443,10 +445,12 @@ __global__ __launch_bounds__(kB) void k_ploc_emit(PlocEmitArgs a) {
         r[0] = make_float4(v0[0], v0[1], v0[2], v1[0]);
         r[1] = make_float4(v1[1], v1[2], v2[0], v2[1]);
         r[2] = make_float4(v2[2], __int_as_float((int32_t)tri), 0.f, 0.f);
-        float4 *q = a.stris + 3 * (size_t)tri;
-        q[0] = r[0];
-        q[1] = r[1];
-        q[2] = make_float4(v2[2], __int_as_float(a.mat_ids[tri]), 0.f, 0.f);
+        if (a.stris) {
+            float4 *q = a.stris + 3 * (size_t)tri;
+            q[0] = r[0];
+            q[1] = r[1];
+            q[2] = make_float4(v2[2], __int_as_float(a.mat_ids[tri]), 0.f, 0.f);
+        }
         return;
     }
     const uint32_t next = pos + 2 * a.t.size[id] - 1;

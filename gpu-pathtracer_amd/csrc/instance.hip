@@ -39,7 +39,27 @@ __global__ __launch_bounds__(256) void k_instance_shading_records(DeviceScene s,
     }
 }
 
+// Child indices of one mesh's two-child nodes from mesh-local to scene-wide (see
+// enter_instance): inner child + node_base; leaf child ~(16-byte position) + 3 * record base.
+__global__ __launch_bounds__(256) void k_rebase_children(int4 *child_words, uint32_t n_nodes,
+                                                         int32_t node_base, int32_t tri_base16) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    int4 c = child_words[4 * (size_t)i + 3];
+    c.x = c.x >= 0 ? c.x + node_base : ~(~c.x + tri_base16);
+    c.y = c.y >= 0 ? c.y + node_base : ~(~c.y + tri_base16);
+    child_words[4 * (size_t)i + 3] = c;
+}
+
 } // namespace
+
+void launch_rebase_children(hipStream_t st, float4 *wnodes, uint32_t n_nodes, uint32_t node_base,
+                            uint32_t tri_record_base) {
+    if (!n_nodes) return;
+    hipLaunchKernelGGL(k_rebase_children, dim3((n_nodes + 255) / 256), dim3(256), 0, st,
+                       reinterpret_cast<int4 *>(wnodes), n_nodes, (int32_t)node_base,
+                       (int32_t)(3 * tri_record_base));
+}
 
 void launch_instance_shading_records(hipStream_t st, const DeviceScene &s,
                                      const float4 *object_to_world, const int32_t *mesh_mat_ids,

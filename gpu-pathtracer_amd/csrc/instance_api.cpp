@@ -18,6 +18,7 @@
 
 #include "../../include/mipt.h"
 #include "../host/bvh.h"
+#include "build.h"
 #include "internal.h"
 
 using namespace mipt;
@@ -25,14 +26,14 @@ using namespace mipt;
 namespace {
 
 int check_meshes(const pt_mesh_desc *meshes, uint32_t n_meshes, const pt_instance *inst,
-                 uint32_t n_inst, const char *who) {
+                 uint32_t n_inst, const char *who, bool need_nodes) {
     if (!meshes || !inst) return fail(PT_ERR_INVALID, std::string(who) + ": null argument");
     if (n_meshes == 0 || n_inst == 0)
         return fail(PT_ERR_INVALID, std::string(who) + ": no meshes or no instances");
     for (uint32_t m = 0; m < n_meshes; ++m) {
         const pt_mesh_desc &d = meshes[m];
-        if (!d.nodes || !d.vertices || !d.indices || d.n_nodes == 0 || d.n_vertices == 0 ||
-            d.n_triangles == 0)
+        if (!d.vertices || !d.indices || d.n_vertices == 0 || d.n_triangles == 0 ||
+            (d.nodes == nullptr) != (d.n_nodes == 0) || (need_nodes && !d.nodes))
             return fail(PT_ERR_INVALID, std::string(who) + ": mesh " + std::to_string(m) +
                                             " is empty or has a null array");
     }
@@ -55,7 +56,7 @@ extern "C" {
 int pt_instance_bounds(const pt_mesh_desc *meshes, uint32_t n_meshes, const pt_instance *instances,
                        uint32_t n_instances, pt_bbox *out) {
     if (!out) return fail(PT_ERR_INVALID, "pt_instance_bounds: null argument");
-    const int rc = check_meshes(meshes, n_meshes, instances, n_instances, "pt_instance_bounds");
+    const int rc = check_meshes(meshes, n_meshes, instances, n_instances, "pt_instance_bounds", true);
     if (rc != PT_OK) return rc;
     for (uint32_t i = 0; i < n_instances; ++i)
         instance_world_box(instances[i].object_to_world, meshes[instances[i].mesh].nodes[0], out[i]);
@@ -67,29 +68,18 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
                               const pt_bbox *top_nodes, uint32_t n_top_nodes,
                               uint32_t link_encoding, const pt_material *materials,
                               uint32_t n_materials, pt_scene **out) {
-    if (!ctx || !top_nodes || !out)
+    if (!ctx || !out || (top_nodes == nullptr) != (n_top_nodes == 0))
         return fail(PT_ERR_INVALID, "pt_scene_create_instanced: null argument");
     *out = nullptr;
-    int rc = check_meshes(meshes, n_meshes, instances, n_instances, "pt_scene_create_instanced");
+    if (link_encoding != PT_LINKS_FLOAT_VALUE && link_encoding != PT_LINKS_INT_BITS)
+        return fail(PT_ERR_INVALID, "pt_scene_create_instanced: unknown link encoding");
+    int rc = check_meshes(meshes, n_meshes, instances, n_instances, "pt_scene_create_instanced", false);
     if (rc != PT_OK) return rc;
     if (materials && n_materials == 0)
         return fail(PT_ERR_INVALID, "pt_scene_create_instanced: materials given but n_materials is 0");
     try {
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-
-        // Top level: a skip-link tree whose leaves name every instance.
-        BvhTree top;
-        tree_from_skip_links(top_nodes, n_top_nodes, link_encoding, n_instances, top);
-        {
-            std::vector<uint8_t> seen(n_instances, 0);
-            for (size_t i = 0; i < top.size(); ++i)
-                if (top.prim[i] >= 0) seen[(size_t)top.prim[i]] = 1;
-            for (uint32_t k = 0; k < n_instances; ++k)
-                if (!seen[k])
-                    return fail(PT_ERR_INVALID, "pt_scene_create_instanced: instance " +
-                                                    std::to_string(k) + " is in no top-level leaf");
-        }
 
         std::vector<pt_material> mats;
         if (materials) {
@@ -101,62 +91,209 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             mats.push_back(m);
         }
 
-        // Meshes, back to back, each validated and re-laid-out like a scene of its own.
-        struct MeshOffsets { uint32_t node, wnode, wtri, vtx, tri; };
-        std::vector<MeshOffsets> off(n_meshes);
-        std::vector<pt_bbox> nodes_all;
-        std::vector<float> vtx_all;
-        std::vector<int32_t> idx_all;
-        std::vector<WideNode> wnodes_all;
-        std::vector<TriRecord> wtris_all;
+        // Meshes, back to back.  One whose tree is given is validated and re-laid-out on the
+        // host like a scene of its own; one without (nodes == NULL) is built on the GPU below.
+        struct MeshPlan {
+            bool on_gpu = false;
+            std::vector<pt_bbox> own_nodes;      // host-built tree of a one-triangle mesh
+            const pt_bbox *nodes = nullptr;      // host copy of the skip-link tree, if any
+            uint32_t n_nodes = 0, n_wnodes = 0, n_wtris = 0;
+            WideBvh wide;
+            uint32_t node = 0, wnode = 0, wtri = 0, vtx = 0, tri = 0;   // offsets
+            pt_bbox root{};
+        };
+        std::vector<MeshPlan> plan(n_meshes);
         uint32_t wide_depth = 0;
+        uint64_t tot_nodes = 0, tot_wnodes = 0, tot_wtris = 0, tot_vtx = 0, tot_tri = 0;
         for (uint32_t m = 0; m < n_meshes; ++m) {
             const pt_mesh_desc &d = meshes[m];
+            MeshPlan &pl = plan[m];
             const std::string tag = "pt_scene_create_instanced: mesh " + std::to_string(m) + ": ";
-            BvhTree tree;
-            try {
-                tree_from_skip_links(d.nodes, d.n_nodes, link_encoding, d.n_triangles, tree);
-            } catch (const std::runtime_error &err) {
-                return fail(PT_ERR_INVALID, tag + err.what());
-            }
-            std::vector<uint8_t> seen(d.n_triangles, 0);
-            for (size_t i = 0; i < tree.size(); ++i)
-                if (tree.prim[i] >= 0) seen[(size_t)tree.prim[i]] = 1;
-            for (uint32_t k = 0; k < d.n_triangles; ++k)
-                if (!seen[k]) return fail(PT_ERR_INVALID, tag + "triangle " + std::to_string(k) + " is in no leaf");
             for (uint64_t i = 0; i < 3ull * d.n_triangles; ++i)
                 if (d.indices[i] < 0 || (uint32_t)d.indices[i] >= d.n_vertices)
                     return fail(PT_ERR_INVALID, tag + "index " + std::to_string(d.indices[i]) +
                                                     " outside the vertex buffer");
-            WideBvh wide;
-            build_wide_layout(tree, d.vertices, d.n_vertices, d.indices, d.n_triangles, wide);
-            if (wnodes_all.size() + wide.nodes.size() > (1u << 26) ||
-                wtris_all.size() + wide.tris.size() > 89000000u)
+            pl.nodes = d.nodes;
+            pl.n_nodes = d.n_nodes;
+            if (!d.nodes && d.n_triangles == 1) {            // a one-leaf tree: nothing to build
+                pl.own_nodes.resize(1);
+                mesh_leaf_bounds(d.vertices, d.indices, 1, pl.own_nodes.data());
+                inflate_leaf_bounds(pl.own_nodes.data(), 1);
+                BvhTree one;
+                pt_bvh_options o;
+                pt_bvh_options_default(&o);
+                build_tree(pl.own_nodes.data(), 1, o, one);
+                linearize_skip_links(one, link_encoding, pl.own_nodes);
+                pl.nodes = pl.own_nodes.data();
+                pl.n_nodes = (uint32_t)pl.own_nodes.size();
+            }
+            if (pl.nodes) {
+                BvhTree tree;
+                try {
+                    tree_from_skip_links(pl.nodes, pl.n_nodes, link_encoding, d.n_triangles, tree);
+                } catch (const std::runtime_error &err) {
+                    return fail(PT_ERR_INVALID, tag + err.what());
+                }
+                std::vector<uint8_t> seen(d.n_triangles, 0);
+                for (size_t i = 0; i < tree.size(); ++i)
+                    if (tree.prim[i] >= 0) seen[(size_t)tree.prim[i]] = 1;
+                for (uint32_t k = 0; k < d.n_triangles; ++k)
+                    if (!seen[k])
+                        return fail(PT_ERR_INVALID, tag + "triangle " + std::to_string(k) + " is in no leaf");
+                build_wide_layout(tree, d.vertices, d.n_vertices, d.indices, d.n_triangles, pl.wide);
+                pl.n_wnodes = (uint32_t)pl.wide.nodes.size();
+                pl.n_wtris = (uint32_t)pl.wide.tris.size();
+                pl.root = pl.nodes[0];
+                if (pl.wide.max_depth > wide_depth) wide_depth = pl.wide.max_depth;
+            } else {
+                if (link_encoding == PT_LINKS_FLOAT_VALUE && 2ull * d.n_triangles - 1 > (1u << 24))
+                    return fail(PT_ERR_INVALID, tag + "more than 2^24 nodes need PT_LINKS_INT_BITS");
+                pl.on_gpu = true;
+                pl.n_nodes = 2 * d.n_triangles - 1;
+                pl.n_wnodes = d.n_triangles - 1;
+                pl.n_wtris = d.n_triangles;
+            }
+            pl.node = (uint32_t)tot_nodes; pl.wnode = (uint32_t)tot_wnodes; pl.wtri = (uint32_t)tot_wtris;
+            pl.vtx = (uint32_t)tot_vtx; pl.tri = (uint32_t)tot_tri;
+            tot_nodes += pl.n_nodes; tot_wnodes += pl.n_wnodes; tot_wtris += pl.n_wtris;
+            tot_vtx += d.n_vertices; tot_tri += d.n_triangles;
+            if (tot_wnodes > (1u << 26) || tot_wtris > 89000000u)
                 return fail(PT_ERR_UNSUPPORTED,
                             "pt_scene_create_instanced: meshes too large together for 32-bit record offsets");
-            // child indices become scene-wide: an inner child is the index of a two-child node,
-            // a leaf child the complement of its record's position in 16-byte units
-            {
-                const int32_t node_base = (int32_t)wnodes_all.size();
-                const int32_t tri_base = 3 * (int32_t)wtris_all.size();
-                for (WideNode &w : wide.nodes)
+            if (tot_nodes > 0x7fffffffull || tot_vtx > 0x7fffffffull)
+                return fail(PT_ERR_UNSUPPORTED, "pt_scene_create_instanced: meshes too large together");
+        }
+
+        auto sc = std::make_unique<pt_scene>();
+        sc->ctx = ctx;
+        auto dev_alloc = [&](size_t bytes) -> void * {
+            void *dst = nullptr;
+            const hipError_t err = hipMalloc(&dst, bytes ? bytes : 16);
+            if (err != hipSuccess) {
+                sc->release();
+                throw std::runtime_error(std::string("pt_scene_create_instanced allocation: ") +
+                                         hipGetErrorString(err));
+            }
+            sc->allocs.push_back(dst);
+            return dst;
+        };
+        auto copy_in = [&](void *dst, const void *src, size_t bytes) {
+            const hipError_t err = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+            if (err != hipSuccess) {
+                sc->release();
+                throw std::runtime_error(std::string("pt_scene_create_instanced upload: ") +
+                                         hipGetErrorString(err));
+            }
+        };
+        auto upload = [&](const void *src, size_t bytes) -> void * {
+            void *dst = dev_alloc(bytes);
+            copy_in(dst, src, bytes);
+            return dst;
+        };
+        char *d_nodes = (char *)dev_alloc(sizeof(pt_bbox) * (size_t)tot_nodes);
+        char *d_vtx = (char *)dev_alloc(sizeof(float) * 3 * (size_t)tot_vtx);
+        char *d_idx = (char *)dev_alloc(sizeof(int32_t) * 3 * (size_t)tot_tri);
+        char *d_wnodes = (char *)dev_alloc(sizeof(WideNode) * (size_t)tot_wnodes);
+        char *d_wtris = (char *)dev_alloc(sizeof(TriRecord) * (size_t)tot_wtris);
+        sc->mesh_node_off.resize(n_meshes);
+        sc->mesh_node_count.resize(n_meshes);
+        DeviceBuffer scratch;
+        for (uint32_t m = 0; m < n_meshes; ++m) {
+            const pt_mesh_desc &d = meshes[m];
+            MeshPlan &pl = plan[m];
+            sc->mesh_node_off[m] = pl.node;
+            sc->mesh_node_count[m] = pl.n_nodes;
+            float *mv = (float *)(d_vtx + sizeof(float) * 3 * (size_t)pl.vtx);
+            int32_t *mi = (int32_t *)(d_idx + sizeof(int32_t) * 3 * (size_t)pl.tri);
+            float4 *mn = (float4 *)(d_nodes + sizeof(pt_bbox) * (size_t)pl.node);
+            float4 *mw = (float4 *)(d_wnodes + sizeof(WideNode) * (size_t)pl.wnode);
+            float4 *mt = (float4 *)(d_wtris + sizeof(TriRecord) * (size_t)pl.wtri);
+            copy_in(mv, d.vertices, sizeof(float) * 3 * (size_t)d.n_vertices);
+            copy_in(mi, d.indices, sizeof(int32_t) * 3 * (size_t)d.n_triangles);
+            if (!pl.on_gpu) {
+                // child indices become scene-wide: an inner child is the index of a two-child
+                // node, a leaf child the complement of its record's position in 16-byte units
+                const int32_t node_base = (int32_t)pl.wnode, tri_base = 3 * (int32_t)pl.wtri;
+                for (WideNode &w : pl.wide.nodes)
                     for (int c = 0; c < 2; ++c)
                         w.child[c] = w.child[c] >= 0 ? w.child[c] + node_base : ~(~w.child[c] + tri_base);
+                copy_in(mn, pl.nodes, sizeof(pt_bbox) * (size_t)pl.n_nodes);
+                copy_in(mw, pl.wide.nodes.data(), sizeof(WideNode) * pl.wide.nodes.size());
+                copy_in(mt, pl.wide.tris.data(), sizeof(TriRecord) * pl.wide.tris.size());
+                pl.wide = WideBvh();
+                continue;
             }
-            if (nodes_all.size() + d.n_nodes > 0x7fffffffull ||
-                vtx_all.size() / 3 + d.n_vertices > 0x7fffffffull ||
-                wtris_all.size() + wide.tris.size() > 0x7fffffffull)
-                return fail(PT_ERR_UNSUPPORTED, "pt_scene_create_instanced: meshes too large together");
-            off[m] = {(uint32_t)nodes_all.size(), (uint32_t)wnodes_all.size(),
-                      (uint32_t)wtris_all.size(), (uint32_t)(vtx_all.size() / 3),
-                      (uint32_t)(idx_all.size() / 3)};
-            nodes_all.insert(nodes_all.end(), d.nodes, d.nodes + d.n_nodes);
-            vtx_all.insert(vtx_all.end(), d.vertices, d.vertices + 3 * (size_t)d.n_vertices);
-            idx_all.insert(idx_all.end(), d.indices, d.indices + 3 * (size_t)d.n_triangles);
-            wnodes_all.insert(wnodes_all.end(), wide.nodes.begin(), wide.nodes.end());
-            wtris_all.insert(wtris_all.end(), wide.tris.begin(), wide.tris.end());
-            if (wide.max_depth > wide_depth) wide_depth = wide.max_depth;
+            {   // the uploads above went through the null stream
+                const hipError_t se = hipDeviceSynchronize();
+                if (se != hipSuccess) {
+                    sc->release();
+                    return hip_fail(se, "pt_scene_create_instanced");
+                }
+            }
+            const DeviceBuildResult br =
+                build_scene_on_device(ctx->stream, mv, mi, d.n_triangles, link_encoding, scratch,
+                                      nullptr, mn, mw, mt, nullptr, ctx->build_ploc_radius);
+            hipError_t err = br.hip_error;
+            if (err == hipSuccess && !br.no_memory && !br.bad_input) {
+                launch_rebase_children(ctx->stream, mw, pl.n_wnodes, pl.wnode, pl.wtri);
+                err = hipGetLastError();
+                if (err == hipSuccess)
+                    err = hipMemcpyAsync(&pl.root, mn, sizeof(pt_bbox), hipMemcpyDeviceToHost, ctx->stream);
+                if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+            }
+            if (br.no_memory || br.bad_input || err != hipSuccess) {
+                (void)hipStreamSynchronize(ctx->stream);
+                scratch.release();
+                sc->release();
+                if (br.bad_input)
+                    return fail(PT_ERR_INVALID, "pt_scene_create_instanced: mesh " + std::to_string(m) +
+                                                    " has a vertex that is not finite");
+                if (br.no_memory) return PT_ERR_DEVICE;       // message set by the failing reserve
+                return hip_fail(err, br.hip_error != hipSuccess ? br.what : "pt_scene_create_instanced build");
+            }
+            if (br.max_depth > wide_depth) wide_depth = br.max_depth;
         }
+        scratch.release();
+
+        // Top level: a skip-link tree whose leaves name every instance; built here (same
+        // builder and inflation as pt_bvh_build, default options) when the caller gives none.
+        std::vector<pt_bbox> own_top;
+        if (!top_nodes) {
+            std::vector<pt_bbox> lb(n_instances);
+            for (uint32_t i = 0; i < n_instances; ++i)
+                instance_world_box(instances[i].object_to_world, plan[instances[i].mesh].root, lb[i]);
+            inflate_leaf_bounds(lb.data(), n_instances);
+            pt_bvh_options o;
+            pt_bvh_options_default(&o);
+            o.use_sah = 1;
+            BvhTree tt;
+            build_tree(lb.data(), n_instances, o, tt);
+            linearize_skip_links(tt, link_encoding, own_top);
+            top_nodes = own_top.data();
+            n_top_nodes = (uint32_t)own_top.size();
+        }
+        BvhTree top;
+        try {
+            tree_from_skip_links(top_nodes, n_top_nodes, link_encoding, n_instances, top);
+        } catch (const std::runtime_error &err) {
+            sc->release();
+            return fail(PT_ERR_INVALID, std::string("pt_scene_create_instanced: top level: ") + err.what());
+        }
+        {
+            std::vector<uint8_t> seen(n_instances, 0);
+            for (size_t i = 0; i < top.size(); ++i)
+                if (top.prim[i] >= 0) seen[(size_t)top.prim[i]] = 1;
+            for (uint32_t k = 0; k < n_instances; ++k)
+                if (!seen[k]) {
+                    sc->release();
+                    return fail(PT_ERR_INVALID, "pt_scene_create_instanced: instance " +
+                                                    std::to_string(k) + " is in no top-level leaf");
+                }
+        }
+        struct MeshOffsets { uint32_t node, wnode, wtri, vtx, tri; };
+        std::vector<MeshOffsets> off(n_meshes);
+        for (uint32_t m = 0; m < n_meshes; ++m)
+            off[m] = {plan[m].node, plan[m].wnode, plan[m].wtri, plan[m].vtx, plan[m].tri};
 
         // Instances.  Their world-space shading records are written on the GPU below; the host
         // only transforms the emissive triangles, for the light list.
@@ -164,7 +301,7 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
         uint32_t max_mesh_tris = 0;
         for (uint32_t i = 0; i < n_instances; ++i) total_tris += meshes[instances[i].mesh].n_triangles;
         if (total_tris > 0x7fffffffull)
-            return fail(PT_ERR_UNSUPPORTED, "pt_scene_create_instanced: more than 2^31 instanced triangles");
+            return sc->release(), fail(PT_ERR_UNSUPPORTED, "pt_scene_create_instanced: more than 2^31 instanced triangles");
         std::vector<int32_t> mesh_mids;                       // per mesh triangle, meshes back to back
         std::vector<std::vector<int32_t>> used_ids(n_meshes); // distinct material ids of each mesh
         bool any_ids = false;
@@ -195,7 +332,7 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             const pt_mesh_desc &d = meshes[in.mesh];
             DeviceInstance &di = dinst[i];
             if (!invert_affine(in.object_to_world, di.inv))
-                return fail(PT_ERR_INVALID, "pt_scene_create_instanced: the transform of instance " +
+                return sc->release(), fail(PT_ERR_INVALID, "pt_scene_create_instanced: the transform of instance " +
                                                 std::to_string(i) + " is not invertible");
             di.node_off = off[in.mesh].node;
             di.wnode_off = off[in.mesh].wnode;
@@ -211,7 +348,7 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             for (int32_t id : used_ids[in.mesh]) {
                 const int64_t mid = (int64_t)id + in.material_offset;
                 if (mid < 0 || mid >= (int64_t)mats.size())
-                    return fail(PT_ERR_INVALID, "pt_scene_create_instanced: instance " +
+                    return sc->release(), fail(PT_ERR_INVALID, "pt_scene_create_instanced: instance " +
                                                     std::to_string(i) + ": material " +
                                                     std::to_string(mid) + " out of range");
                 const pt_material &pm = mats[(size_t)mid];
@@ -246,28 +383,12 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             for (int32_t &t : light_tri) t = light_ids[(size_t)t];
         }
 
-        auto sc = std::make_unique<pt_scene>();
-        sc->ctx = ctx;
-        auto upload = [&](const void *src, size_t bytes) -> void * {
-            void *dst = nullptr;
-            hipError_t err = hipMalloc(&dst, bytes);
-            if (err == hipSuccess) {
-                sc->allocs.push_back(dst);
-                err = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
-            }
-            if (err != hipSuccess) {
-                sc->release();
-                throw std::runtime_error(std::string("pt_scene_create_instanced upload: ") +
-                                         hipGetErrorString(err));
-            }
-            return dst;
-        };
         DeviceScene &d = sc->dev;
-        d.nodes = (const float4 *)upload(nodes_all.data(), sizeof(pt_bbox) * nodes_all.size());
-        d.vtx = (const float *)upload(vtx_all.data(), sizeof(float) * vtx_all.size());
-        d.idx = (const int32_t *)upload(idx_all.data(), sizeof(int32_t) * idx_all.size());
-        d.wnodes = (const float4 *)upload(wnodes_all.data(), sizeof(WideNode) * wnodes_all.size());
-        d.wtris = (const float4 *)upload(wtris_all.data(), sizeof(TriRecord) * wtris_all.size());
+        d.nodes = (const float4 *)d_nodes;
+        d.vtx = (const float *)d_vtx;
+        d.idx = (const int32_t *)d_idx;
+        d.wnodes = (const float4 *)d_wnodes;
+        d.wtris = (const float4 *)d_wtris;
         void *d_stris = nullptr;
         {
             const hipError_t err = hipMalloc(&d_stris, sizeof(TriRecord) * (size_t)total_tris);
@@ -290,9 +411,9 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
         }
         d.n_lights = (uint32_t)light_tri.size();
         d.light_area = light_cdf.empty() ? 0.f : light_cdf.back();
-        d.n_nodes = (uint32_t)nodes_all.size();
+        d.n_nodes = (uint32_t)tot_nodes;
         d.n_tri = (uint32_t)total_tris;
-        d.n_wnodes = (uint32_t)wnodes_all.size();
+        d.n_wnodes = (uint32_t)tot_wnodes;
         d.n_materials = (uint32_t)mats.size();
         d.link_enc = link_encoding;
         d.wide_depth = wide_depth;
@@ -341,5 +462,35 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
 }
 
 uint32_t pt_scene_instance_count(const pt_scene *scene) { return scene ? scene->dev.n_instances : 0; }
+
+uint32_t pt_scene_top_node_count(const pt_scene *scene) { return scene ? scene->dev.n_tlas_nodes : 0; }
+
+int pt_scene_read_top_nodes(pt_scene *scene, pt_bbox *nodes) {
+    if (!scene || !nodes) return fail(PT_ERR_INVALID, "pt_scene_read_top_nodes: null argument");
+    if (!scene->dev.tlas) return fail(PT_ERR_INVALID, "pt_scene_read_top_nodes: not a two-level scene");
+    hipError_t e = hipSetDevice(scene->ctx->device);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(nodes, scene->dev.tlas, sizeof(pt_bbox) * (size_t)scene->dev.n_tlas_nodes,
+                           hipMemcpyDeviceToHost, scene->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(scene->ctx->stream);
+    return e == hipSuccess ? PT_OK : hip_fail(e, "pt_scene_read_top_nodes");
+}
+
+uint32_t pt_scene_mesh_node_count(const pt_scene *scene, uint32_t mesh) {
+    return scene && mesh < scene->mesh_node_count.size() ? scene->mesh_node_count[mesh] : 0;
+}
+
+int pt_scene_read_mesh_nodes(pt_scene *scene, uint32_t mesh, pt_bbox *nodes) {
+    if (!scene || !nodes) return fail(PT_ERR_INVALID, "pt_scene_read_mesh_nodes: null argument");
+    if (mesh >= scene->mesh_node_count.size())
+        return fail(PT_ERR_INVALID, "pt_scene_read_mesh_nodes: no such mesh");
+    hipError_t e = hipSetDevice(scene->ctx->device);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(nodes, scene->dev.nodes + 2 * (size_t)scene->mesh_node_off[mesh],
+                           sizeof(pt_bbox) * (size_t)scene->mesh_node_count[mesh], hipMemcpyDeviceToHost,
+                           scene->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(scene->ctx->stream);
+    return e == hipSuccess ? PT_OK : hip_fail(e, "pt_scene_read_mesh_nodes");
+}
 
 } // extern "C"

@@ -88,8 +88,11 @@ struct pt_scene {
     pt_context *ctx = nullptr;
     mipt::DeviceScene dev{};
     std::vector<void *> allocs;
+    // two-level scenes: where each mesh's skip-link nodes lie in dev.nodes
+    std::vector<uint32_t> mesh_node_off, mesh_node_count;
     void release() {
         for (void *p : allocs) (void)hipFree(p);
         allocs.clear();
     }
+    ~pt_scene() { release(); }
 };

@@ -95,6 +95,11 @@ void launch_instance_shading_records(hipStream_t st, const DeviceScene &s,
                                      const int32_t *material_offset, uint32_t max_mesh_tris,
                                      float4 *stris);
 
+// Makes the child indices of n_nodes two-child nodes scene-wide: the mesh's nodes start at
+// node_base, its triangle records at tri_record_base (in records).
+void launch_rebase_children(hipStream_t st, float4 *wnodes, uint32_t n_nodes, uint32_t node_base,
+                            uint32_t tri_record_base);
+
 // Workgroups of `block` threads a persistent kernel may launch and still have them all
 // resident: compute units x min(cap, what the occupancy query admits).
 unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg, int *cache);

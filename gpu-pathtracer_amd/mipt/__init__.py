@@ -144,6 +144,10 @@ _PROTOS = {
                                             C.POINTER(Instance), C.c_uint32, _vp, C.c_uint32,
                                             C.c_uint32, _vp, C.c_uint32, C.POINTER(_vp)]),
     "pt_scene_instance_count": (C.c_uint32, [_vp]),
+    "pt_scene_top_node_count": (C.c_uint32, [_vp]),
+    "pt_scene_read_top_nodes": (C.c_int, [_vp, _vp]),
+    "pt_scene_mesh_node_count": (C.c_uint32, [_vp, C.c_uint32]),
+    "pt_scene_read_mesh_nodes": (C.c_int, [_vp, C.c_uint32, _vp]),
     "pt_scene_node_count": (C.c_uint32, [_vp]),
     "pt_scene_link_encoding": (C.c_uint32, [_vp]),
     "pt_scene_read_nodes": (C.c_int, [_vp, _vp]),
@@ -399,15 +403,17 @@ class Scene:
                   material_offsets=None, link_encoding: int = PT_LINKS_FLOAT_VALUE) -> "Scene":
         """``pt_scene_create_instanced``.  meshes: [(nodes, vtx, idx, material_ids or None)];
         transforms: [n, 3, 4] object-to-world; mesh_of: mesh index per instance; top_nodes:
-        skip-link tree over ``instance_bounds(...)``."""
+        skip-link tree over ``instance_bounds(...)``.  A mesh whose nodes are None is built on
+        the GPU; top_nodes None: the top level is built by the library."""
         descs, insts, keep = _instance_args(meshes, transforms, mesh_of, material_offsets)
-        top = _as(top_nodes, bbox_dtype, "top_nodes")
+        top = _as(top_nodes, bbox_dtype, "top_nodes") if top_nodes is not None else None
         mats = _as(materials, material_dtype, "materials") if materials is not None else None
         self = cls.__new__(cls)
         self.ctx = ctx
         self._h = _vp()
         _check(lib.pt_scene_create_instanced(
-            ctx._h, descs, len(descs), insts, len(insts), _ptr(top), top.shape[0], link_encoding,
+            ctx._h, descs, len(descs), insts, len(insts), _ptr(top) if top is not None else None,
+            top.shape[0] if top is not None else 0, link_encoding,
             _ptr(mats) if mats is not None else None, mats.shape[0] if mats is not None else 0,
             C.byref(self._h)))
         self.n_tri = sum(int(descs[m].n_triangles) for m in mesh_of)
@@ -415,6 +421,16 @@ class Scene:
 
     def instance_count(self) -> int:
         return int(lib.pt_scene_instance_count(self._h))
+
+    def read_top_nodes(self) -> np.ndarray:
+        out = np.empty(lib.pt_scene_top_node_count(self._h), dtype=bbox_dtype)
+        _check(lib.pt_scene_read_top_nodes(self._h, _ptr(out)))
+        return out
+
+    def read_mesh_nodes(self, mesh: int) -> np.ndarray:
+        out = np.empty(lib.pt_scene_mesh_node_count(self._h, mesh), dtype=bbox_dtype)
+        _check(lib.pt_scene_read_mesh_nodes(self._h, mesh, _ptr(out)))
+        return out
 
     def read_nodes(self) -> np.ndarray:
         """The scene's skip-link node array."""
@@ -469,13 +485,15 @@ def _instance_args(meshes, transforms, mesh_of, material_offsets=None):
     for k, mesh in enumerate(meshes):
         nodes, vtx, idx = mesh[0], mesh[1], mesh[2]
         mids = mesh[3] if len(mesh) > 3 else None
-        nodes = _as(nodes, bbox_dtype, "nodes")
+        if nodes is not None:
+            nodes = _as(nodes, bbox_dtype, "nodes")
         vtx = _as(vtx, np.float32, "vtx").reshape(-1, 3)
         idx = _as(idx, np.int32, "idx").reshape(-1, 3)
         keep += [nodes, vtx, idx]
-        descs[k].nodes, descs[k].vertices, descs[k].indices = _ptr(nodes), _ptr(vtx), _ptr(idx)
-        descs[k].n_nodes, descs[k].n_vertices, descs[k].n_triangles = \
-            nodes.shape[0], vtx.shape[0], idx.shape[0]
+        descs[k].nodes = _ptr(nodes) if nodes is not None else None
+        descs[k].vertices, descs[k].indices = _ptr(vtx), _ptr(idx)
+        descs[k].n_nodes = nodes.shape[0] if nodes is not None else 0
+        descs[k].n_vertices, descs[k].n_triangles = vtx.shape[0], idx.shape[0]
         if mids is not None:
             mids = _as(mids, np.int32, "material_ids")
             if mids.shape[0] != idx.shape[0]:

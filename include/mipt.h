@@ -227,7 +227,8 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
  * same in both spaces.  A hit reports shapeid = instance index and primid = triangle of the
  * instance's mesh.  Shading uses the world-space vertices M v (same operation order). */
 typedef struct pt_mesh_desc {
-    const pt_bbox *nodes;        /* the mesh's skip-link BVH, as for pt_scene_create */
+    const pt_bbox *nodes;        /* the mesh's skip-link BVH, as for pt_scene_create; NULL (with
+                                    n_nodes 0) to have it built on the GPU, as pt_scene_build does */
     const float *vertices;       /* xyz packed, object space */
     const int32_t *indices;      /* 3 per triangle */
     const int32_t *material_ids; /* per triangle, or NULL (all 0) */
@@ -243,14 +244,22 @@ typedef struct pt_instance {
 int pt_instance_bounds(const pt_mesh_desc *meshes, uint32_t n_meshes, const pt_instance *instances,
                        uint32_t n_instances, pt_bbox *out);
 /* top_nodes: skip-link tree over the instances (leaf payload = instance index), all trees in
- * the same link_encoding.  materials may be NULL (one grey diffuse material).  The scene
- * works with every pt_trace_* and pt_render call (PT_TRACE_MOLLER_TRUMBORE excepted). */
+ * the same link_encoding; NULL (with n_top_nodes 0) to have it built here, by the builder of
+ * pt_bvh_build with its default options over the boxes of pt_instance_bounds.  materials may
+ * be NULL (one grey diffuse material).  The scene works with every pt_trace_* and pt_render
+ * call (PT_TRACE_MOLLER_TRUMBORE excepted). */
 int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint32_t n_meshes,
                               const pt_instance *instances, uint32_t n_instances,
                               const pt_bbox *top_nodes, uint32_t n_top_nodes,
                               uint32_t link_encoding, const pt_material *materials,
                               uint32_t n_materials, pt_scene **out);
 uint32_t pt_scene_instance_count(const pt_scene *scene);   /* 0 for a single-level scene */
+/* The trees of a two-level scene, given or built (for validation, caching, or a CPU walk of the
+ * same trees).  Blocking. */
+uint32_t pt_scene_top_node_count(const pt_scene *scene);
+int pt_scene_read_top_nodes(pt_scene *scene, pt_bbox *nodes);
+uint32_t pt_scene_mesh_node_count(const pt_scene *scene, uint32_t mesh);
+int pt_scene_read_mesh_nodes(pt_scene *scene, uint32_t mesh, pt_bbox *nodes);
 
 /* The scene's skip-link array (what pt_scene_create was given, or what pt_scene_build made):
  * for validation, caching, or a CPU traversal of the same tree.  Blocking. */

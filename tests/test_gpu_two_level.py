@@ -101,6 +101,52 @@ def test_render_matches_the_cpu_restatement(mipt, oracle, gpu_ctx, flags):
         scene.close()
 
 
+@pytest.mark.parametrize("encoding", ["float", "int"])
+def test_trees_built_by_the_library(mipt, oracle, gpu_ctx, encoding):
+    """No tree from the caller: meshes built on the GPU (the single-triangle mesh and the
+    quad included), top level built by the library.  The CPU restatement walks the trees read
+    back from the scene and must agree bit for bit; hits also agree with the scene whose trees
+    the host builder made, wherever no two candidates tie."""
+    sc = tl.scene()
+    enc = mipt.PT_LINKS_INT_BITS if encoding == "int" else mipt.PT_LINKS_FLOAT_VALUE
+    meshes = [(None, v, i, m) for v, i, m in sc["meshes"]]
+    scene = mipt.Scene.instanced(gpu_ctx, meshes, sc["transforms"], sc["mesh_of"], None,
+                                 materials=tl.materials(mipt), material_offsets=sc["material_offsets"],
+                                 link_encoding=enc)
+    t_ref, ref_scene = _build(mipt, oracle, gpu_ctx, sc)
+    try:
+        top = scene.read_top_nodes()
+        trees = [scene.read_mesh_nodes(k) for k in range(len(meshes))]
+        for k, (_, v, i, _) in enumerate(meshes):
+            assert trees[k].shape[0] == 2 * i.shape[0] - 1
+            mipt.validate_bvh(trees[k], i.shape[0], enc)
+        mipt.validate_bvh(top, len(sc["mesh_of"]), enc)
+        rays = tl.rays_for(40000, 8, mipt.ray_dtype)
+        got = scene.trace_closest(rays)
+        assert same_hits(scene.trace_closest(rays, flags=mipt.PT_TRACE_EXACT_ORDER), got, nan_equal=True).size == 0
+        if encoding == "float":       # the restatement reads float-valued links only
+            t = oracle.TwoLevel([(trees[k], v, i) for k, (_, v, i, _) in enumerate(meshes)],
+                                sc["transforms"], sc["mesh_of"], top)
+            assert same_hits(got, t.closest(rays, nthreads=8), nan_equal=True).size == 0
+            np.testing.assert_array_equal(scene.trace_any(rays), t.any_hit(rays, nthreads=8))
+        # against the host-built trees: same instance and triangle except at ties
+        other = ref_scene.trace_closest(rays)
+        same = (got["shapeid"] == other["shapeid"]) & (got["primid"] == other["primid"])
+        assert same[4:].mean() > 0.99
+        hit = (got["primid"] >= 0) & (other["primid"] >= 0)
+        np.testing.assert_allclose(got["uvwt"][hit, 3][4:], other["uvwt"][hit, 3][4:], rtol=1e-5)
+        # and the path tracer runs on it
+        film = mipt.Film(gpu_ctx, 64, 48)
+        cam = mipt.look_at_camera((0.0, 3.0, -14.0), (0.0, 0.5, 0.0), fovy_deg=45.0, aspect=64 / 48)
+        st = mipt.render(gpu_ctx, scene, cam, mipt.render_params(64, 48, sample_count=4, max_depth=4, seed=2,
+                                                                 flags=mipt.PT_RENDER_NEE), film, stats=True)
+        assert st.rays_shadow > 0 and np.isfinite(film.read()).all() and film.read()[..., :3].mean() > 0
+        film.close()
+    finally:
+        scene.close()
+        ref_scene.close()
+
+
 def test_integer_bit_links(mipt, oracle, gpu_ctx):
     """All trees in the integer-bit-pattern link encoding (src/bvh/bvh_builder.h:29-33 as
     documented): same hits as with float-valued links."""
