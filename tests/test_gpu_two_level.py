@@ -101,6 +101,33 @@ def test_render_matches_the_cpu_restatement(mipt, oracle, gpu_ctx, flags):
         scene.close()
 
 
+def test_single_identity_instance_equals_the_flat_scene(mipt, oracle, scenes, gpu_ctx):
+    """One instance, identity transform: object space is world space, so the two-level scene
+    returns the flat scene's hits bit for bit (its one-leaf top level names the instance in
+    both children of its only two-child node)."""
+    vtx, idx, _ = tl.blob_mesh(500, 12)
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx))
+    ident = np.zeros((1, 3, 4), dtype=np.float32)
+    ident[0, :, :3] = np.eye(3)
+    flat = mipt.Scene(gpu_ctx, nodes, vtx, idx)
+    top = mipt.build_bvh(mipt.instance_bounds([(nodes, vtx, idx)], ident, [0]))
+    assert top.shape[0] == 1
+    two = mipt.Scene.instanced(gpu_ctx, [(nodes, vtx, idx)], ident, [0], top)
+    try:
+        rays = tl.rays_for(30000, 3, mipt.ray_dtype)[4:]
+        rays["o"][:, :3] *= 0.3
+        a, b = two.trace_closest(rays), flat.trace_closest(rays)
+        hit = b["primid"] >= 0
+        assert hit.sum() > 3000
+        np.testing.assert_array_equal(a["primid"], b["primid"])
+        np.testing.assert_array_equal(a["uvwt"][hit].view(np.uint32), b["uvwt"][hit].view(np.uint32))
+        np.testing.assert_array_equal(a["shapeid"], np.where(hit, 0, -1))
+        np.testing.assert_array_equal(two.trace_any(rays), flat.trace_any(rays))
+    finally:
+        two.close()
+        flat.close()
+
+
 @pytest.mark.parametrize("encoding", ["float", "int"])
 def test_trees_built_by_the_library(mipt, oracle, gpu_ctx, encoding):
     """No tree from the caller: meshes built on the GPU (the single-triangle mesh and the
