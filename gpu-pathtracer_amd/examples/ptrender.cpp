@@ -35,12 +35,12 @@ static void cross(const double a[3], const double b[3], double out[3]) {
 int main(int argc, char **argv) {
     if (argc < 3) {
         std::fprintf(stderr, "usage: ptrender scene.obj out.ppm|.png|.pfm [--size W H] [--spp N] [--depth D] "
-                             "[--nee] [--gpu-build] [--eye x y z] [--target x y z] [--fov deg] "
+                             "[--nee] [--gpu-build] [--instanced] [--eye x y z] [--target x y z] [--fov deg] "
                              "[--seed S] [--film out.raw]\n");
         return 2;
     }
     uint32_t W = 512, H = 512, spp = 16, depth = 4, seed = 1;
-    bool nee = false, gpu_build = false;
+    bool nee = false, gpu_build = false, instanced = false;
     double eye[3] = {278, 273, -800}, target[3] = {278, 273, 0}, fov = 39.3;
     const char *film_path = nullptr;
     for (int i = 3; i < argc; ++i) {
@@ -56,42 +56,67 @@ int main(int argc, char **argv) {
         else if (a == "--film") { need(1); film_path = argv[++i]; }
         else if (a == "--nee") nee = true;
         else if (a == "--gpu-build") gpu_build = true;
+        else if (a == "--instanced") instanced = true;
         else { std::fprintf(stderr, "ptrender: unknown option %s\n", a.c_str()); return 2; }
     }
 
-    pt_mesh *mesh = nullptr;
     const std::string scene_path = argv[1];
     auto ends_with = [&](const char *suffix) {
         const size_t n = std::strlen(suffix);
         return scene_path.size() >= n && scene_path.compare(scene_path.size() - n, n, suffix) == 0;
     };
-    if (ends_with(".glb") || ends_with(".gltf")) CHECK(pt_gltf_load(argv[1], 0, &mesh));   // src/main_granite.cpp:268
-    else CHECK(pt_obj_load(argv[1], &mesh));
-    const uint32_t n_vtx = pt_mesh_vertex_count(mesh), n_tri = pt_mesh_triangle_count(mesh);
-    std::printf("%s: %u vertices, %u triangles, %u materials\n", argv[1], n_vtx, n_tri,
-                pt_mesh_material_count(mesh));
-
+    const bool gltf = ends_with(".glb") || ends_with(".gltf");
     pt_context *ctx = nullptr;
     CHECK(pt_context_create(0, &ctx));
     pt_scene *scene = nullptr;
-    if (gpu_build) {
-        CHECK(pt_scene_build(ctx, pt_mesh_vertices(mesh), n_vtx, pt_mesh_indices(mesh), n_tri,
-                             pt_mesh_materials(mesh), pt_mesh_material_count(mesh),
-                             pt_mesh_material_ids(mesh), PT_LINKS_INT_BITS, &scene));
+    pt_mesh *mesh = nullptr;
+    if (instanced) {
+        // the glTF scene as structured: each mesh once, its nodes as instances; every tree is
+        // left to the library (meshes on the GPU, top level on the host)
+        if (!gltf) { std::fprintf(stderr, "ptrender: --instanced needs a glTF scene\n"); return 2; }
+        pt_model *model = nullptr;
+        CHECK(pt_gltf_load_model(argv[1], &model));
+        std::vector<pt_mesh_desc> descs(pt_model_mesh_count(model));
+        for (uint32_t k = 0; k < descs.size(); ++k) {
+            const pt_mesh *m = pt_model_mesh(model, k);
+            std::memset(&descs[k], 0, sizeof(pt_mesh_desc));
+            descs[k].vertices = pt_mesh_vertices(m);
+            descs[k].indices = pt_mesh_indices(m);
+            descs[k].material_ids = pt_mesh_material_ids(m);
+            descs[k].n_vertices = pt_mesh_vertex_count(m);
+            descs[k].n_triangles = pt_mesh_triangle_count(m);
+        }
+        std::printf("%s: %u meshes, %u instances, %u materials\n", argv[1], (unsigned)descs.size(),
+                    pt_model_instance_count(model), pt_model_material_count(model));
+        CHECK(pt_scene_create_instanced(ctx, descs.data(), (uint32_t)descs.size(), pt_model_instances(model),
+                                        pt_model_instance_count(model), nullptr, 0, PT_LINKS_INT_BITS,
+                                        pt_model_materials(model), pt_model_material_count(model), &scene));
+        pt_model_destroy(model);
     } else {
-        std::vector<pt_bbox> leaves(n_tri);
-        CHECK(pt_mesh_leaf_bounds(pt_mesh_vertices(mesh), n_vtx, pt_mesh_indices(mesh), n_tri, leaves.data()));
-        pt_bvh_options opt;
-        pt_bvh_options_default(&opt);
-        CHECK(pt_bvh_options_set(&opt, "bvh.builder", "sah"));       // src/main_granite.cpp:176
-        CHECK(pt_bvh_options_set(&opt, "mipt.link_encoding", "int"));
-        pt_bvh *bvh = nullptr;
-        CHECK(pt_bvh_build(leaves.data(), n_tri, &opt, &bvh));
-        CHECK(pt_scene_create(ctx, pt_bvh_nodes(bvh), pt_bvh_node_count(bvh), pt_bvh_link_encoding(bvh),
-                              pt_mesh_vertices(mesh), n_vtx, pt_mesh_indices(mesh), n_tri,
-                              pt_mesh_materials(mesh), pt_mesh_material_count(mesh),
-                              pt_mesh_material_ids(mesh), &scene));
-        pt_bvh_destroy(bvh);
+        if (gltf) CHECK(pt_gltf_load(argv[1], 0, &mesh));   // src/main_granite.cpp:268
+        else CHECK(pt_obj_load(argv[1], &mesh));
+        const uint32_t n_vtx = pt_mesh_vertex_count(mesh), n_tri = pt_mesh_triangle_count(mesh);
+        std::printf("%s: %u vertices, %u triangles, %u materials\n", argv[1], n_vtx, n_tri,
+                    pt_mesh_material_count(mesh));
+        if (gpu_build) {
+            CHECK(pt_scene_build(ctx, pt_mesh_vertices(mesh), n_vtx, pt_mesh_indices(mesh), n_tri,
+                                 pt_mesh_materials(mesh), pt_mesh_material_count(mesh),
+                                 pt_mesh_material_ids(mesh), PT_LINKS_INT_BITS, &scene));
+        } else {
+            std::vector<pt_bbox> leaves(n_tri);
+            CHECK(pt_mesh_leaf_bounds(pt_mesh_vertices(mesh), n_vtx, pt_mesh_indices(mesh), n_tri, leaves.data()));
+            pt_bvh_options opt;
+            pt_bvh_options_default(&opt);
+            CHECK(pt_bvh_options_set(&opt, "bvh.builder", "sah"));       // src/main_granite.cpp:176
+            CHECK(pt_bvh_options_set(&opt, "mipt.link_encoding", "int"));
+            pt_bvh *bvh = nullptr;
+            CHECK(pt_bvh_build(leaves.data(), n_tri, &opt, &bvh));
+            CHECK(pt_scene_create(ctx, pt_bvh_nodes(bvh), pt_bvh_node_count(bvh), pt_bvh_link_encoding(bvh),
+                                  pt_mesh_vertices(mesh), n_vtx, pt_mesh_indices(mesh), n_tri,
+                                  pt_mesh_materials(mesh), pt_mesh_material_count(mesh),
+                                  pt_mesh_material_ids(mesh), &scene));
+            pt_bvh_destroy(bvh);
+        }
     }
 
     // look-at camera: columns of mat3(inv_view) are right, up, back

@@ -253,8 +253,11 @@ Mat4 node_matrix(const Json &node) {
 struct Gltf {
     Json doc;
     std::vector<std::vector<unsigned char>> buffers;
-    pt_mesh *out = nullptr;
-    std::vector<int> material_map;      // glTF material -> index in out->materials, -1 = not yet
+    pt_mesh *out = nullptr;             // mesh that primitive() appends to
+    std::vector<pt_material> *mats = nullptr;   // material list that material() appends to
+    pt_model *model = nullptr;          // set: keep meshes in object space and record instances
+    std::vector<int> mesh_map;          // glTF mesh -> index in model->meshes, -1 = not yet, -2 = empty
+    std::vector<int> material_map;      // glTF material -> index in *mats, -1 = not yet
     int default_material = -1;
     bool first_only = false, done = false;
 
@@ -302,8 +305,8 @@ struct Gltf {
                 pt_material m{};
                 m.kd[0] = m.kd[1] = m.kd[2] = 0.5f;
                 m.roughness = 1.f;
-                default_material = (int)out->materials.size();
-                out->materials.push_back(m);
+                default_material = (int)mats->size();
+                mats->push_back(m);
             }
             return default_material;
         }
@@ -329,8 +332,8 @@ struct Gltf {
             m.ke[k] = (float)(em[k] * strength);
         }
         m.roughness = (float)rough;
-        material_map[(size_t)gm] = (int)out->materials.size();
-        out->materials.push_back(m);
+        material_map[(size_t)gm] = (int)mats->size();
+        mats->push_back(m);
         return material_map[(size_t)gm];
     }
 
@@ -388,7 +391,31 @@ struct Gltf {
         const Json &n = at("nodes", ni);
         const Mat4 world = mul(parent, node_matrix(n));
         const long mi = n.index("mesh");
-        if (mi >= 0) {
+        if (mi >= 0 && model) {
+            // every mesh once, in its own space; the node becomes an instance of it
+            if ((size_t)mi >= mesh_map.size()) throw std::runtime_error("node.mesh out of range");
+            if (mesh_map[(size_t)mi] == -1) {
+                auto fresh = std::make_unique<pt_mesh>();
+                out = fresh.get();
+                if (const Json *prims = at("meshes", mi).get("primitives"))
+                    for (const Json &p : prims->arr) primitive(p, nullptr);
+                out = nullptr;
+                if (fresh->idx.empty()) {
+                    mesh_map[(size_t)mi] = -2;
+                } else {
+                    mesh_map[(size_t)mi] = (int)model->meshes.size();
+                    model->meshes.push_back(fresh.release());
+                }
+            }
+            if (mesh_map[(size_t)mi] >= 0) {
+                pt_instance in{};
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 4; ++c) in.object_to_world[4 * r + c] = (float)world.m[4 * c + r];
+                in.mesh = (uint32_t)mesh_map[(size_t)mi];
+                in.material_offset = 0;
+                model->instances.push_back(in);
+            }
+        } else if (mi >= 0) {
             const Json &mesh = at("meshes", mi);
             if (const Json *prims = mesh.get("primitives"))
                 for (const Json &p : prims->arr) {
@@ -403,80 +430,92 @@ struct Gltf {
 
 } // namespace
 
+// Reads the file at path into g (document and buffers); returns PT_OK or fails.
+static int open_gltf(const char *path, const char *who, Gltf &g) {
+    std::vector<unsigned char> file;
+    if (!read_file(path, file))
+        return mipt::fail(PT_ERR_IO, std::string(who) + ": cannot open '" + path + "'");
+    const unsigned char *json = file.data();
+    size_t json_len = file.size();
+    const unsigned char *bin = nullptr;
+    size_t bin_len = 0;
+    if (file.size() >= 12 && rd32(file.data()) == 0x46546C67u) {           // "glTF": binary container
+        if (rd32(file.data() + 4) != 2) return mipt::fail(PT_ERR_UNSUPPORTED, std::string(who) + ": only glTF version 2");
+        size_t off = 12;
+        json = nullptr;
+        while (off + 8 <= file.size()) {
+            const size_t len = rd32(file.data() + off);
+            const uint32_t type = rd32(file.data() + off + 4);
+            if (off + 8 + len > file.size()) return mipt::fail(PT_ERR_IO, std::string(who) + ": truncated chunk");
+            if (type == 0x4E4F534Au && !json) { json = file.data() + off + 8; json_len = len; }
+            else if (type == 0x004E4942u && !bin) { bin = file.data() + off + 8; bin_len = len; }
+            off += 8 + ((len + 3) & ~(size_t)3);
+        }
+        if (!json) return mipt::fail(PT_ERR_IO, std::string(who) + ": no JSON chunk");
+    }
+    JsonParser jp{reinterpret_cast<const char *>(json), reinterpret_cast<const char *>(json) + json_len};
+    g.doc = jp.value();
+    if (g.doc.type != Json::Obj) return mipt::fail(PT_ERR_INVALID, std::string(who) + ": the document is not an object");
+
+    std::string dir(path);
+    const size_t slash = dir.find_last_of("/\\");
+    dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+    for (const Json &b : g.array("buffers").arr) {
+        const Json *uri = b.get("uri");
+        std::vector<unsigned char> data;
+        if (!uri) {
+            if (!bin) return mipt::fail(PT_ERR_INVALID, std::string(who) + ": buffer without uri outside a .glb");
+            data.assign(bin, bin + bin_len);
+        } else if (uri->str.compare(0, 5, "data:") == 0) {
+            const size_t comma = uri->str.find(',');
+            if (comma == std::string::npos) return mipt::fail(PT_ERR_INVALID, std::string(who) + ": malformed data URI");
+            data = base64(uri->str, comma + 1);
+        } else if (!read_file(dir + uri->str, data)) {
+            return mipt::fail(PT_ERR_IO, std::string(who) + ": cannot open buffer '" + dir + uri->str + "'");
+        }
+        if (data.size() < (size_t)b.number("byteLength", 0))
+            return mipt::fail(PT_ERR_IO, std::string(who) + ": buffer shorter than its byteLength");
+        g.buffers.push_back(std::move(data));
+    }
+    g.material_map.assign(g.array("materials").size(), -1);
+    g.mesh_map.assign(g.array("meshes").size(), -1);
+    return PT_OK;
+}
+
+// Walks the default scene's roots, else every node that is nobody's child.
+static void walk_scene(Gltf &g) {
+    std::vector<long> roots;
+    const Json &scenes = g.array("scenes");
+    if (scenes.size()) {
+        long si = g.doc.index("scene");
+        if (si < 0) si = 0;
+        if (const Json *rn = g.at("scenes", si).get("nodes"))
+            for (const Json &r : rn->arr) roots.push_back((long)r.num);
+    } else {
+        const Json &nodes = g.array("nodes");
+        std::vector<char> is_child(nodes.size(), 0);
+        for (const Json &n : nodes.arr)
+            if (const Json *ch = n.get("children"))
+                for (const Json &c : ch->arr)
+                    if (c.num >= 0 && (size_t)c.num < is_child.size()) is_child[(size_t)c.num] = 1;
+        for (size_t i = 0; i < nodes.size(); ++i)
+            if (!is_child[i]) roots.push_back((long)i);
+    }
+    for (long r : roots) g.node(r, identity(), 0);
+}
+
 extern "C" int pt_gltf_load(const char *path, uint32_t flags, pt_mesh **out) {
     if (!path || !out) return mipt::fail(PT_ERR_INVALID, "pt_gltf_load: null argument");
     *out = nullptr;
     try {
-        std::vector<unsigned char> file;
-        if (!read_file(path, file))
-            return mipt::fail(PT_ERR_IO, std::string("pt_gltf_load: cannot open '") + path + "'");
         Gltf g;
-        const unsigned char *json = file.data();
-        size_t json_len = file.size();
-        const unsigned char *bin = nullptr;
-        size_t bin_len = 0;
-        if (file.size() >= 12 && rd32(file.data()) == 0x46546C67u) {           // "glTF": binary container
-            if (rd32(file.data() + 4) != 2) return mipt::fail(PT_ERR_UNSUPPORTED, "pt_gltf_load: only glTF version 2");
-            size_t off = 12;
-            json = nullptr;
-            while (off + 8 <= file.size()) {
-                const size_t len = rd32(file.data() + off);
-                const uint32_t type = rd32(file.data() + off + 4);
-                if (off + 8 + len > file.size()) return mipt::fail(PT_ERR_IO, "pt_gltf_load: truncated chunk");
-                if (type == 0x4E4F534Au && !json) { json = file.data() + off + 8; json_len = len; }
-                else if (type == 0x004E4942u && !bin) { bin = file.data() + off + 8; bin_len = len; }
-                off += 8 + ((len + 3) & ~(size_t)3);
-            }
-            if (!json) return mipt::fail(PT_ERR_IO, "pt_gltf_load: no JSON chunk");
-        }
-        JsonParser jp{reinterpret_cast<const char *>(json), reinterpret_cast<const char *>(json) + json_len};
-        g.doc = jp.value();
-        if (g.doc.type != Json::Obj) return mipt::fail(PT_ERR_INVALID, "pt_gltf_load: the document is not an object");
-
-        std::string dir(path);
-        const size_t slash = dir.find_last_of("/\\");
-        dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
-        for (const Json &b : g.array("buffers").arr) {
-            const Json *uri = b.get("uri");
-            std::vector<unsigned char> data;
-            if (!uri) {
-                if (!bin) return mipt::fail(PT_ERR_INVALID, "pt_gltf_load: buffer without uri outside a .glb");
-                data.assign(bin, bin + bin_len);
-            } else if (uri->str.compare(0, 5, "data:") == 0) {
-                const size_t comma = uri->str.find(',');
-                if (comma == std::string::npos) return mipt::fail(PT_ERR_INVALID, "pt_gltf_load: malformed data URI");
-                data = base64(uri->str, comma + 1);
-            } else if (!read_file(dir + uri->str, data)) {
-                return mipt::fail(PT_ERR_IO, "pt_gltf_load: cannot open buffer '" + dir + uri->str + "'");
-            }
-            if (data.size() < (size_t)b.number("byteLength", 0))
-                return mipt::fail(PT_ERR_IO, "pt_gltf_load: buffer shorter than its byteLength");
-            g.buffers.push_back(std::move(data));
-        }
-
+        const int rc = open_gltf(path, "pt_gltf_load", g);
+        if (rc != PT_OK) return rc;
         auto mesh = std::make_unique<pt_mesh>();
         g.out = mesh.get();
-        g.material_map.assign(g.array("materials").size(), -1);
+        g.mats = &mesh->materials;
         g.first_only = (flags & PT_GLTF_FIRST_MESH_ONLY) != 0;
-        // roots: the default scene's, else every node that is nobody's child
-        std::vector<long> roots;
-        const Json &scenes = g.array("scenes");
-        if (scenes.size()) {
-            long si = g.doc.index("scene");
-            if (si < 0) si = 0;
-            if (const Json *rn = g.at("scenes", si).get("nodes"))
-                for (const Json &r : rn->arr) roots.push_back((long)r.num);
-        } else {
-            const Json &nodes = g.array("nodes");
-            std::vector<char> is_child(nodes.size(), 0);
-            for (const Json &n : nodes.arr)
-                if (const Json *ch = n.get("children"))
-                    for (const Json &c : ch->arr)
-                        if (c.num >= 0 && (size_t)c.num < is_child.size()) is_child[(size_t)c.num] = 1;
-            for (size_t i = 0; i < nodes.size(); ++i)
-                if (!is_child[i]) roots.push_back((long)i);
-        }
-        for (long r : roots) g.node(r, identity(), 0);
+        walk_scene(g);
         if (mesh->idx.empty()) return mipt::fail(PT_ERR_INVALID, "pt_gltf_load: no triangles in the scene");
         *out = mesh.release();
         return PT_OK;
@@ -486,3 +525,42 @@ extern "C" int pt_gltf_load(const char *path, uint32_t flags, pt_mesh **out) {
         return mipt::fail(PT_ERR_INVALID, std::string("pt_gltf_load: ") + e.what());
     }
 }
+
+extern "C" {
+
+int pt_gltf_load_model(const char *path, pt_model **out) {
+    if (!path || !out) return mipt::fail(PT_ERR_INVALID, "pt_gltf_load_model: null argument");
+    *out = nullptr;
+    try {
+        Gltf g;
+        const int rc = open_gltf(path, "pt_gltf_load_model", g);
+        if (rc != PT_OK) return rc;
+        auto model = std::make_unique<pt_model>();
+        g.model = model.get();
+        g.mats = &model->materials;
+        walk_scene(g);
+        if (model->instances.empty())
+            return mipt::fail(PT_ERR_INVALID, "pt_gltf_load_model: no triangles in the scene");
+        *out = model.release();
+        return PT_OK;
+    } catch (const std::bad_alloc &) {
+        return mipt::fail(PT_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return mipt::fail(PT_ERR_INVALID, std::string("pt_gltf_load_model: ") + e.what());
+    }
+}
+
+uint32_t pt_model_mesh_count(const pt_model *m) { return m ? (uint32_t)m->meshes.size() : 0; }
+const pt_mesh *pt_model_mesh(const pt_model *m, uint32_t i) {
+    return m && i < m->meshes.size() ? m->meshes[i] : nullptr;
+}
+uint32_t pt_model_instance_count(const pt_model *m) { return m ? (uint32_t)m->instances.size() : 0; }
+const pt_instance *pt_model_instances(const pt_model *m) { return m ? m->instances.data() : nullptr; }
+uint32_t pt_model_material_count(const pt_model *m) { return m ? (uint32_t)m->materials.size() : 0; }
+const pt_material *pt_model_materials(const pt_model *m) { return m ? m->materials.data() : nullptr; }
+int pt_model_destroy(pt_model *m) {
+    delete m;
+    return PT_OK;
+}
+
+} // extern "C"

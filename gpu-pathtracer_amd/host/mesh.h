@@ -12,3 +12,14 @@ struct pt_mesh {
     std::vector<int32_t> mat_ids;       // 1 per triangle
     std::vector<pt_material> materials;
 };
+
+// A scene kept as structured: every mesh once, in its own space, plus the instances that
+// place them (filled by pt_gltf_load_model).
+struct pt_model {
+    std::vector<pt_mesh *> meshes;          // owned; their mat_ids index `materials`
+    std::vector<pt_instance> instances;
+    std::vector<pt_material> materials;
+    ~pt_model() {
+        for (pt_mesh *m : meshes) delete m;
+    }
+};

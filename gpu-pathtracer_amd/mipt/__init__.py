@@ -144,6 +144,14 @@ _PROTOS = {
                                             C.POINTER(Instance), C.c_uint32, _vp, C.c_uint32,
                                             C.c_uint32, _vp, C.c_uint32, C.POINTER(_vp)]),
     "pt_scene_instance_count": (C.c_uint32, [_vp]),
+    "pt_gltf_load_model": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "pt_model_mesh_count": (C.c_uint32, [_vp]),
+    "pt_model_mesh": (_vp, [_vp, C.c_uint32]),
+    "pt_model_instance_count": (C.c_uint32, [_vp]),
+    "pt_model_instances": (C.POINTER(Instance), [_vp]),
+    "pt_model_material_count": (C.c_uint32, [_vp]),
+    "pt_model_materials": (_vp, [_vp]),
+    "pt_model_destroy": (C.c_int, [_vp]),
     "pt_scene_top_node_count": (C.c_uint32, [_vp]),
     "pt_scene_read_top_nodes": (C.c_int, [_vp, _vp]),
     "pt_scene_mesh_node_count": (C.c_uint32, [_vp, C.c_uint32]),
@@ -320,6 +328,38 @@ class Mesh:
 
 
 # ---------------------------------------------------------------- device side
+class Model:
+    """``pt_gltf_load_model``: .meshes = [(vtx, idx, material_ids)], .transforms [n,3,4],
+    .mesh_of, .materials -- the arguments of ``Scene.instanced`` (trees left to the library)."""
+
+    def __init__(self, path: str):
+        h = _vp()
+        _check(lib.pt_gltf_load_model(path.encode(), C.byref(h)))
+        try:
+            self.meshes = []
+            for k in range(lib.pt_model_mesh_count(h)):
+                m = lib.pt_model_mesh(h, k)
+                nv, nt = lib.pt_mesh_vertex_count(m), lib.pt_mesh_triangle_count(m)
+                vtx = np.ctypeslib.as_array(C.cast(lib.pt_mesh_vertices(m), C.POINTER(C.c_float)), (nv, 3)).copy()
+                idx = np.ctypeslib.as_array(C.cast(lib.pt_mesh_indices(m), C.POINTER(C.c_int32)), (nt, 3)).copy()
+                mids = np.ctypeslib.as_array(C.cast(lib.pt_mesh_material_ids(m), C.POINTER(C.c_int32)), (nt,)).copy()
+                self.meshes.append((vtx, idx, mids))
+            n = lib.pt_model_instance_count(h)
+            inst = lib.pt_model_instances(h)
+            self.transforms = np.array([[inst[i].object_to_world[j] for j in range(12)] for i in range(n)],
+                                       dtype=np.float32).reshape(n, 3, 4)
+            self.mesh_of = [int(inst[i].mesh) for i in range(n)]
+            nm = lib.pt_model_material_count(h)
+            self.materials = np.frombuffer(
+                C.string_at(lib.pt_model_materials(h), nm * material_dtype.itemsize), dtype=material_dtype).copy()
+        finally:
+            lib.pt_model_destroy(h)
+
+    def scene(self, ctx: "Context", link_encoding: int = PT_LINKS_FLOAT_VALUE) -> "Scene":
+        return Scene.instanced(ctx, [(None, v, i, m) for v, i, m in self.meshes], self.transforms,
+                               self.mesh_of, None, materials=self.materials, link_encoding=link_encoding)
+
+
 class Context:
     def __init__(self, device: int = 0):
         self._h = _vp()

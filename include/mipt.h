@@ -50,6 +50,7 @@ extern "C" {
 typedef struct pt_context pt_context;
 typedef struct pt_bvh pt_bvh;
 typedef struct pt_mesh pt_mesh;
+typedef struct pt_model pt_model;
 typedef struct pt_scene pt_scene;
 typedef struct pt_film pt_film;
 
@@ -254,6 +255,19 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
                               uint32_t link_encoding, const pt_material *materials,
                               uint32_t n_materials, pt_scene **out);
 uint32_t pt_scene_instance_count(const pt_scene *scene);   /* 0 for a single-level scene */
+/* A glTF 2.0 / GLB scene kept as it is structured (pt_gltf_load flattens it instead): every
+ * mesh that a node shows, once, in its own space (all its triangle-list primitives), and one
+ * instance per showing node with the node hierarchy composed into object_to_world -- the
+ * arrays pt_scene_create_instanced takes (material_offset 0: the meshes' material ids index
+ * pt_model_materials).  Meshes are owned by the model; read them with pt_mesh_*. */
+int pt_gltf_load_model(const char *path, pt_model **out);
+uint32_t pt_model_mesh_count(const pt_model *m);
+const pt_mesh *pt_model_mesh(const pt_model *m, uint32_t i);
+uint32_t pt_model_instance_count(const pt_model *m);
+const pt_instance *pt_model_instances(const pt_model *m);
+uint32_t pt_model_material_count(const pt_model *m);
+const pt_material *pt_model_materials(const pt_model *m);
+int pt_model_destroy(pt_model *m);
 /* The trees of a two-level scene, given or built (for validation, caching, or a CPU walk of the
  * same trees).  Blocking. */
 uint32_t pt_scene_top_node_count(const pt_scene *scene);

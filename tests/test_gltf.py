@@ -127,3 +127,109 @@ def test_gltf_errors(mipt, tmp_path):
     open(path, "w").write(json.dumps(doc))
     with pytest.raises(mipt.MiptError, match="shorter than"):
         mipt.Mesh(path)
+
+
+def _instanced_document(tmp_path):
+    """One quad mesh shown by three nodes (one of them nested), one triangle mesh shown once,
+    and a mesh no node shows."""
+    path, quad, quad_idx, tri = _document(tmp_path, "external")
+    doc = json.loads(open(path).read())
+    doc["nodes"] = [
+        {"mesh": 0, "translation": [10, 0, 0], "scale": [2, 2, 2], "children": [1, 2]},
+        {"mesh": 1, "rotation": [0, 0, 0.7071067811865476, 0.7071067811865476]},
+        {"mesh": 0, "translation": [0, 3, 0]},
+        {"mesh": 0, "matrix": [1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, 0, -4, 1, 2, 1]},
+    ]
+    doc["scenes"] = [{"nodes": [0, 3]}]
+    doc["meshes"].append({"primitives": [{"attributes": {"POSITION": 2}}]})      # unused
+    open(path, "w").write(json.dumps(doc))
+    return path, quad, quad_idx, tri
+
+
+def test_gltf_model_keeps_meshes_and_instances(mipt, oracle, tmp_path):
+    """pt_gltf_load_model: every shown mesh once in its own space, one instance per showing
+    node; placing the meshes by the instances gives the flattened load's vertices."""
+    path, quad, quad_idx, tri = _instanced_document(tmp_path)
+    model = mipt.Model(path)
+    assert len(model.meshes) == 2 and model.mesh_of == [0, 1, 0, 0]
+    np.testing.assert_array_equal(model.meshes[0][0], quad)
+    np.testing.assert_array_equal(model.meshes[0][1].reshape(-1), quad_idx.astype(np.int32))
+    np.testing.assert_array_equal(model.meshes[1][0], tri)
+    np.testing.assert_array_equal(model.meshes[0][2], [0, 0])
+    np.testing.assert_array_equal(model.meshes[1][2], [1])
+    assert model.materials.shape[0] == 2
+    np.testing.assert_allclose(model.transforms[0], [[2, 0, 0, 10], [0, 2, 0, 0], [0, 0, 2, 0]], atol=1e-6)
+    np.testing.assert_allclose(model.transforms[2], [[2, 0, 0, 10], [0, 2, 0, 6], [0, 0, 2, 0]], atol=1e-6)
+    np.testing.assert_allclose(model.transforms[3], [[1, 0, 0, -4], [0, 0, -1, 1], [0, 1, 0, 2]], atol=1e-6)
+    flat = mipt.Mesh(path)
+    placed = np.concatenate([oracle.transform_points(model.transforms[k], model.meshes[m][0])
+                             for k, m in enumerate(model.mesh_of)])
+    np.testing.assert_allclose(placed, flat.vtx, rtol=0, atol=2e-5)
+    assert flat.idx.shape[0] == sum(model.meshes[m][1].shape[0] for m in model.mesh_of)
+
+
+@pytest.mark.gpu
+def test_gltf_model_as_a_two_level_scene(mipt, gpu_ctx, tmp_path):
+    """The model's scene (trees built by the library) and the flattened scene see the same
+    surfaces: same hit distances for rays aimed at them, instance and mesh triangle reported."""
+    path, *_ = _instanced_document(tmp_path)
+    model = mipt.Model(path)
+    two = model.scene(gpu_ctx)
+    flat_mesh = mipt.Mesh(path)
+    flat = mipt.Scene(gpu_ctx, None, flat_mesh.vtx, flat_mesh.idx, flat_mesh.materials, flat_mesh.material_ids)
+    try:
+        assert two.instance_count() == 4
+        rng = np.random.default_rng(4)
+        n = 20000
+        tri = rng.integers(0, flat_mesh.idx.shape[0], n)
+        w = rng.dirichlet([1, 1, 1], n).astype(np.float32)
+        target = (flat_mesh.vtx[flat_mesh.idx[tri]] * w[:, :, None]).sum(1)
+        rays = np.zeros(n, dtype=mipt.ray_dtype)
+        rays["o"][:, :3] = target + rng.normal(size=(n, 3)).astype(np.float32) * 3
+        d = target - rays["o"][:, :3]
+        rays["d"][:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        rays["o"][:, 3] = 1e30
+        a, b = two.trace_closest(rays), flat.trace_closest(rays)
+        both = (a["primid"] >= 0) & (b["primid"] >= 0)
+        assert both.mean() > 0.95 and ((a["primid"] >= 0) != (b["primid"] >= 0)).mean() < 0.01
+        np.testing.assert_allclose(a["uvwt"][both, 3], b["uvwt"][both, 3], rtol=1e-4, atol=1e-4)
+        first = np.cumsum([0] + [model.meshes[m][1].shape[0] for m in model.mesh_of])[:-1]
+        glob = first[a["shapeid"][both]] + a["primid"][both]
+        assert (glob == b["primid"][both]).mean() > 0.97       # coplanar neighbours may swap
+    finally:
+        two.close()
+        flat.close()
+
+
+@pytest.mark.gpu
+def test_cpp_host_program_renders_the_instanced_model(mipt, gpu_ctx, tmp_path):
+    """examples/ptrender.cpp --instanced: glTF model -> pt_scene_create_instanced with every tree
+    left to the library -> render; the film equals the Python binding's on the same calls."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "..", "gpu-pathtracer_amd", "ptrender")
+    if not os.path.exists(exe):
+        pytest.fail("gpu-pathtracer_amd/ptrender is not built (make -C gpu-pathtracer_amd ptrender)")
+    path, *_ = _instanced_document(tmp_path)
+    W, H = 80, 60
+    raw, png = str(tmp_path / "f.raw"), str(tmp_path / "o.png")
+    view = ["--eye", "6", "4", "14", "--target", "8", "2", "0", "--fov", "60"]
+    out = subprocess.run([exe, path, png, "--instanced", "--size", str(W), str(H), "--spp", "4", "--depth", "3",
+                          "--nee", "--seed", "3", "--film", raw] + view, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "2 meshes, 4 instances" in out.stdout
+    got = np.fromfile(raw, dtype=np.float32).reshape(H, W, 4)
+    two = mipt.Model(path).scene(gpu_ctx, link_encoding=mipt.PT_LINKS_INT_BITS)
+    film = mipt.Film(gpu_ctx, W, H)
+    try:
+        cam = mipt.look_at_camera((6.0, 4.0, 14.0), (8.0, 2.0, 0.0), fovy_deg=60.0, aspect=W / H)
+        mipt.render(gpu_ctx, two, cam, mipt.render_params(W, H, sample_count=4, max_depth=3, seed=3,
+                                                          flags=mipt.PT_RENDER_NEE), film)
+        want = film.read()
+        np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert want[..., :3].sum() > 0          # the emissive triangle is in view or lights something
+    finally:
+        film.close()
+        two.close()
+    assert open(png, "rb").read()[:8] == b"\x89PNG\r\n\x1a\n"

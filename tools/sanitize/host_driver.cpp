@@ -129,11 +129,18 @@ int main() {
         check(pt_gltf_load((dir + "t.gltf").c_str(), 0, &m) == PT_OK, "glTF with a base64 buffer");
         check(m->idx.size() == 3 && m->vtx.size() == 9 && m->vtx[3] == 2.f, "glTF contents");
         pt_mesh_destroy(m);
+        pt_model *mo = nullptr;
+        check(pt_gltf_load_model((dir + "t.gltf").c_str(), &mo) == PT_OK, "glTF as meshes + instances");
+        check(pt_model_mesh_count(mo) == 1 && pt_model_instance_count(mo) >= 1 &&
+              pt_mesh_triangle_count(pt_model_mesh(mo, 0)) == 1, "glTF model contents");
+        pt_model_destroy(mo);
     }
     for (size_t len = 0; len < gltf.size(); len += 3) {
         { std::ofstream(dir + "t.gltf") << gltf.substr(0, len); }
         pt_mesh *m = nullptr;
         if (pt_gltf_load((dir + "t.gltf").c_str(), 0, &m) == PT_OK) pt_mesh_destroy(m);
+        pt_model *mo = nullptr;
+        if (pt_gltf_load_model((dir + "t.gltf").c_str(), &mo) == PT_OK) pt_model_destroy(mo);
     }
     std::puts("host code clean under ASan + UBSan");
     return 0;
