@@ -96,6 +96,7 @@ void pt_bvh_options_default(pt_bvh_options *opt) {
     opt->extra_node_budget = 0.5f;  // :32
     opt->link_encoding = PT_LINKS_FLOAT_VALUE;
     opt->num_threads = 0;
+    opt->optimize_passes = 0;
 }
 
 int pt_bvh_options_set(pt_bvh_options *opt, const char *key, const char *value) {
@@ -131,6 +132,7 @@ int pt_bvh_build(const pt_bbox *leaf_bounds, uint32_t n_leaves, const pt_bvh_opt
     inflate_leaf_bounds(scaled.data(), n_leaves);
     BvhTree tree;
     build_tree(scaled.data(), n_leaves, o, tree);
+    optimize_tree(tree, o.optimize_passes);
     auto bvh = std::make_unique<pt_bvh>();
     bvh->link_encoding = o.link_encoding;
     linearize_skip_links(tree, o.link_encoding, bvh->nodes);

@@ -268,6 +268,7 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             o.use_sah = 1;
             BvhTree tt;
             build_tree(lb.data(), n_instances, o, tt);
+            optimize_tree(tt, 2);
             linearize_skip_links(tt, link_encoding, own_top);
             top_nodes = own_top.data();
             n_top_nodes = (uint32_t)own_top.size();

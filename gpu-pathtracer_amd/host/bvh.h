@@ -85,6 +85,12 @@ void build_light_list(const float *vtx, const int32_t *idx, uint32_t n_tri,
                       const pt_material *materials, const int32_t *material_ids,
                       std::vector<int32_t> &tri, std::vector<float> &cdf);
 
+// Insertion-based optimisation of a built tree (bvh_optimize.cpp): `passes` rounds of taking every
+// subtree out and putting it back where it adds the least surface area.  Leaf boxes unchanged.
+void optimize_tree(BvhTree &t, int passes);
+// Sum of the inner nodes' surface areas over the root's (the SAH's traversal term).
+double tree_area_cost(const BvhTree &t);
+
 void build_wide_top(const BvhTree &t, std::vector<WideNode> &out);
 
 // Two-level scenes (instances.cpp).  m, inv: 3x4, three rows of (linear part | translation).

@@ -587,6 +587,10 @@ bool set_option(pt_bvh_options &opt, const std::string &key, const std::string &
     } else if (key == "mipt.num_threads") {
         if (!as_float(f)) return false;
         opt.num_threads = (int)f;
+    } else if (key == "mipt.optimize_passes") {
+        if (!as_float(f)) return false;
+        if (f < 0.f || f > 64.f) { err = "option 'mipt.optimize_passes' must be in [0, 64]"; return false; }
+        opt.optimize_passes = (int)f;
     } else {
         err = "unknown option '" + key + "'";
         return false;

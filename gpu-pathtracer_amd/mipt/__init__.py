@@ -50,7 +50,7 @@ class BvhOptions(C.Structure):
     _fields_ = [("use_sah", C.c_int32), ("use_splits", C.c_int32), ("max_split_depth", C.c_int32),
                 ("num_bins", C.c_int32), ("min_overlap", C.c_float), ("traversal_cost", C.c_float),
                 ("extra_node_budget", C.c_float), ("link_encoding", C.c_uint32),
-                ("num_threads", C.c_int32)]
+                ("num_threads", C.c_int32), ("optimize_passes", C.c_int32)]
 
 
 class Camera(C.Structure):

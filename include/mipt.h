@@ -76,6 +76,8 @@ typedef struct pt_bvh_options {
     float   extra_node_budget;  /* "bvh.sah.extra_node_budget"               default 0.5 */
     uint32_t link_encoding;     /* PT_LINKS_*                                default FLOAT_VALUE */
     int32_t num_threads;        /* host threads for the build, 0 = all cores */
+    int32_t optimize_passes;    /* "mipt.optimize_passes": rounds of insertion-based optimisation
+                                   of the finished tree (not in the reference)   default 0 */
 } pt_bvh_options;
 
 /* Work counters of one trace call, summed over its rays. */
@@ -246,7 +248,7 @@ int pt_instance_bounds(const pt_mesh_desc *meshes, uint32_t n_meshes, const pt_i
                        uint32_t n_instances, pt_bbox *out);
 /* top_nodes: skip-link tree over the instances (leaf payload = instance index), all trees in
  * the same link_encoding; NULL (with n_top_nodes 0) to have it built here, by the builder of
- * pt_bvh_build with its default options over the boxes of pt_instance_bounds.  materials may
+ * pt_bvh_build (SAH, two optimisation passes) over the boxes of pt_instance_bounds.  materials may
  * be NULL (one grey diffuse material).  The scene works with every pt_trace_* and pt_render
  * call (PT_TRACE_MOLLER_TRUMBORE excepted). */
 int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint32_t n_meshes,

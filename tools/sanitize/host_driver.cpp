@@ -76,6 +76,12 @@ int main() {
             check(set_option(opt, "bvh.sah.max_split_depth", "16", err), "set_option");
             BvhTree tree;
             build_tree(lb.data(), n, opt, tree);
+            if (variant == 1) {
+                const double before = tree_area_cost(tree);
+                optimize_tree(tree, 2);
+                check(tree.size() == 2 * (size_t)n - 1 || opt.use_splits, "optimised tree size");
+                check(tree_area_cost(tree) <= before * 1.0000001, "optimised tree area");
+            }
             for (uint32_t enc : {PT_LINKS_FLOAT_VALUE, PT_LINKS_INT_BITS}) {
                 std::vector<pt_bbox> nodes;
                 linearize_skip_links(tree, enc, nodes);
