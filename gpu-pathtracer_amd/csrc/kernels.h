@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/mipt.h"
 
 namespace mipt {
@@ -102,7 +104,8 @@ void launch_rebase_children(hipStream_t st, float4 *wnodes, uint32_t n_nodes, ui
 
 // Workgroups of `block` threads a persistent kernel may launch and still have them all
 // resident: compute units x min(cap, what the occupancy query admits).
-unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg, int *cache);
+unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg,
+                             std::atomic<int> *cache);
 
 // Occlusion query.  exact_order: walk the skip links as the reference does; otherwise the
 // two-child nodes, nearer child first (the answer is the same).

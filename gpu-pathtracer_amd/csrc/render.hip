@@ -12,6 +12,7 @@
 #include "render.h"
 
 #include <algorithm>
+#include <atomic>
 
 #include "pt_camera_math.h"
 #include "pt_shade_math.h"
@@ -363,7 +364,7 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
                       DeviceTraceCounters *work, const ExtendConfig &cfg) {
     if (!max_rays) return;
     if (s.tlas && cfg.persistent_blocks > 0) {
-        static int occ2[2] = {0, 0};
+        static std::atomic<int> occ2[2];
         const void *k = work ? (const void *)k_pt_extend_two_level_persistent<true>
                              : (const void *)k_pt_extend_two_level_persistent<false>;
         const unsigned int grid = (unsigned int)std::min<uint64_t>(
@@ -386,7 +387,7 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
         return;
     }
     if (cfg.persistent_blocks > 0) {
-        static int occ[2] = {0, 0};
+        static std::atomic<int> occ[2];
         const void *k = work ? (const void *)k_pt_extend_persistent<true>
                              : (const void *)k_pt_extend_persistent<false>;
         const unsigned int grid = (unsigned int)std::min<uint64_t>(
@@ -421,7 +422,7 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
                        const ExtendConfig &cfg) {
     if (!max_rays) return;
     if (s.tlas && cfg.persistent_blocks > 0) {
-        static int occ2 = 0;
+        static std::atomic<int> occ2{0};
         const unsigned int grid = (unsigned int)std::min<uint64_t>(
             blocks(max_rays, kBlock),
             persistent_grid((const void *)k_pt_occlude_two_level_persistent, kBlock, cfg, &occ2));
@@ -435,7 +436,7 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
         return;
     }
     if (cfg.persistent_blocks > 0) {
-        static int occ = 0;
+        static std::atomic<int> occ{0};
         const unsigned int grid = (unsigned int)std::min<uint64_t>(
             blocks(max_rays, kBlock),
             persistent_grid((const void *)k_pt_occlude_persistent, kBlock, cfg, &occ));

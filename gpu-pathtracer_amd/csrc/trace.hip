@@ -6,6 +6,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 
 namespace mipt {
 
@@ -197,15 +198,18 @@ inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kBlock - 1
 
 } // namespace
 
-unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg, int *cache) {
+unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg,
+                             std::atomic<int> *cache) {
     // Never launch more persistent workgroups than can be resident at once: the surplus
     // would only start after the first ones have finished their whole streams.
-    if (*cache == 0) {
+    int per_cu = cache->load(std::memory_order_relaxed);
+    if (per_cu == 0) {               // contexts on several GPUs may get here at once: same answer
         int nb = 0;
         const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0);
-        *cache = (e == hipSuccess && nb > 0) ? nb : 4;
+        per_cu = (e == hipSuccess && nb > 0) ? nb : 4;
+        cache->store(per_cu, std::memory_order_relaxed);
     }
-    return (unsigned int)(cfg.num_cus * std::min(*cache, cfg.blocks_per_cu));
+    return (unsigned int)(cfg.num_cus * std::min(per_cu, cfg.blocks_per_cu));
 }
 
 void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
@@ -235,7 +239,7 @@ void launch_trace_two_level(hipStream_t st, const DeviceScene &s, const pt_ray *
                             bool count_work, const ExtendConfig &cfg) {
     if (n == 0) return;
     if (!exact && cfg.persistent_blocks > 0) {
-        static int occ[2] = {0, 0};
+        static std::atomic<int> occ[2];
         const void *k = count_work ? (const void *)k_trace_two_level_persistent<true>
                                    : (const void *)k_trace_two_level_persistent<false>;
         const unsigned int grid = (unsigned int)std::min<uint64_t>(
@@ -284,7 +288,7 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
             }
             // on any failure the rays are simply taken in queue order
         }
-        static int occ[2] = {0, 0};
+        static std::atomic<int> occ[2];
         const void *k = count_work ? (const void *)k_trace_ordered_persistent<true>
                                    : (const void *)k_trace_ordered_persistent<false>;
         const unsigned int grid = (unsigned int)std::min<uint64_t>(
@@ -311,7 +315,7 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
     if (n == 0) return;
     if (s.tlas) {
         if (!exact_order && cfg.persistent_blocks > 0) {
-            static int occ2 = 0;
+            static std::atomic<int> occ2{0};
             const unsigned int grid = (unsigned int)std::min<uint64_t>(
                 grid_for(n),
                 persistent_grid((const void *)k_trace_any_two_level_persistent, kBlock, cfg, &occ2));
@@ -325,7 +329,7 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
     }
     const bool wide = !exact_order && s.n_tri >= 2;
     if (wide && cfg.persistent_blocks > 0) {
-        static int occ = 0;
+        static std::atomic<int> occ{0};
         const unsigned int grid = (unsigned int)std::min<uint64_t>(
             grid_for(n), persistent_grid((const void *)k_trace_any_persistent, kBlock, cfg, &occ));
         hipLaunchKernelGGL(k_trace_any_persistent, dim3(grid), dim3(kBlock), 0, st, s, rays, occluded,

@@ -319,3 +319,38 @@ def test_tree_with_spatial_splits_on_device(mipt, oracle, scenes, gpu_ctx):
         np.testing.assert_array_equal(sc.trace_any(rays), oracle.any_hit(nodes, vtx, idx, rays, nthreads=8))
     finally:
         sc.close()
+
+
+def test_two_contexts_driven_from_two_threads(mipt, oracle, scenes):
+    """One context per host thread (the threading contract of the C ABI): both threads trace
+    and render at the same time on the same GPU and get the single-threaded answers."""
+    import threading
+    vtx, idx, mats, mids = scenes.atrium(65536, seed=3)
+    nodes = _build(mipt, vtx, idx)
+    rays = scenes.surface_rays(vtx, idx, 200_000, seed=1).astype(mipt.ray_dtype)
+    want = oracle.closest(nodes, vtx, idx, rays, nthreads=8)
+    cam = scenes.atrium_camera(1.5)
+    results, errors = {}, []
+
+    def work(k):
+        try:
+            ctx = mipt.Context(0)
+            sc = mipt.Scene(ctx, nodes, vtx, idx, mats, mids)
+            film = mipt.Film(ctx, 96, 64)
+            hits = [sc.trace_closest(rays) for _ in range(3)]
+            mipt.render(ctx, sc, cam, mipt.render_params(96, 64, sample_count=4, max_depth=4, seed=5), film)
+            results[k] = (hits, film.read())
+            film.close(); sc.close(); ctx.close()
+        except Exception as e:          # surfaced below: an exception in a thread is otherwise lost
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        for h in results[k][0]:
+            assert len(same_hits(h, want)) == 0
+    np.testing.assert_array_equal(results[0][1].view(np.uint32), results[1][1].view(np.uint32))
