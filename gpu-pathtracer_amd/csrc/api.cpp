@@ -141,6 +141,23 @@ int pt_bvh_build(const pt_bbox *leaf_bounds, uint32_t n_leaves, const pt_bvh_opt
     PT_CATCH
 }
 
+int pt_bvh_optimize(const pt_bbox *nodes, uint32_t n_nodes, uint32_t link_encoding, int32_t passes,
+                    pt_bvh **out) {
+    if (!nodes || !out) return fail(PT_ERR_INVALID, "pt_bvh_optimize: null argument");
+    *out = nullptr;
+    if (passes < 0 || passes > 64) return fail(PT_ERR_INVALID, "pt_bvh_optimize: passes must be in [0, 64]");
+    PT_TRY
+    BvhTree tree;
+    tree_from_skip_links(nodes, n_nodes, link_encoding, 0, tree);
+    optimize_tree(tree, passes);
+    auto bvh = std::make_unique<pt_bvh>();
+    bvh->link_encoding = link_encoding;
+    linearize_skip_links(tree, link_encoding, bvh->nodes);
+    *out = bvh.release();
+    return PT_OK;
+    PT_CATCH
+}
+
 uint32_t pt_bvh_node_count(const pt_bvh *bvh) { return bvh ? (uint32_t)bvh->nodes.size() : 0; }
 const pt_bbox *pt_bvh_nodes(const pt_bvh *bvh) { return bvh ? bvh->nodes.data() : nullptr; }
 uint32_t pt_bvh_link_encoding(const pt_bvh *bvh) { return bvh ? bvh->link_encoding : 0; }

@@ -109,6 +109,7 @@ _PROTOS = {
     "pt_bvh_options_set": (C.c_int, [C.POINTER(BvhOptions), C.c_char_p, C.c_char_p]),
     "pt_mesh_leaf_bounds": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint32, _vp]),
     "pt_bvh_build": (C.c_int, [_vp, C.c_uint32, C.POINTER(BvhOptions), C.POINTER(_vp)]),
+    "pt_bvh_optimize": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(_vp)]),
     "pt_bvh_node_count": (C.c_uint32, [_vp]),
     "pt_bvh_nodes": (_vp, [_vp]),
     "pt_bvh_link_encoding": (C.c_uint32, [_vp]),
@@ -250,6 +251,14 @@ def build_bvh(leaf_bounds, options: Optional[BvhOptions] = None) -> np.ndarray:
         return np.frombuffer(src, dtype=bbox_dtype).copy()
     finally:
         lib.pt_bvh_destroy(h)
+
+
+def optimize_bvh(nodes, passes: int = 2, link_encoding: int = PT_LINKS_FLOAT_VALUE) -> np.ndarray:
+    """``pt_bvh_optimize``: insertion-based optimisation of any skip-link tree."""
+    nodes = _as(nodes, bbox_dtype, "nodes")
+    h = _vp()
+    _check(lib.pt_bvh_optimize(_ptr(nodes), nodes.shape[0], link_encoding, passes, C.byref(h)))
+    return _take_nodes(h)
 
 
 def _take_nodes(h) -> np.ndarray:

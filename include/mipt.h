@@ -126,6 +126,11 @@ int pt_mesh_leaf_bounds(const float *vtx, uint32_t n_vtx, const int32_t *idx, ui
  * linearizes it into 2n-1 skip-link nodes (format: src/bvh/bvh_builder.h:26-34). */
 int pt_bvh_build(const pt_bbox *leaf_bounds, uint32_t n_leaves, const pt_bvh_options *opt,
                  pt_bvh **out);
+/* The insertion-based optimisation of "mipt.optimize_passes" applied to any skip-link tree (one
+ * built elsewhere, or read back from pt_scene_build): same leaves, rearranged above them.  Not
+ * in the reference. */
+int pt_bvh_optimize(const pt_bbox *nodes, uint32_t n_nodes, uint32_t link_encoding, int32_t passes,
+                    pt_bvh **out);
 uint32_t pt_bvh_node_count(const pt_bvh *bvh);
 /* vector<bbox> returned by build_bvh; valid until pt_bvh_destroy. */
 const pt_bbox *pt_bvh_nodes(const pt_bvh *bvh);

@@ -306,3 +306,6 @@ def test_insertion_optimisation_keeps_leaves_and_answers(mipt, oracle, scenes):
     assert (a["primid"] >= 0).mean() > 0.5
     with pytest.raises(mipt.MiptError, match="optimize_passes"):
         mipt.bvh_options(**{"mipt.optimize_passes": 1000})
+    # the same pass on a tree handed in (pt_bvh_optimize): what the option does inside the build
+    again = mipt.optimize_bvh(plain, 2)
+    np.testing.assert_array_equal(again.view(np.uint32), better.view(np.uint32))
