@@ -22,11 +22,12 @@ struct DeviceBuildResult {
 // vertices with the material id, in the caller's triangle order; skipped if d_stris is null).
 // ploc_radius 0: binary
 // radix tree over the Morton codes; > 0: locally-ordered clustering with that search radius.
+// optimize_passes > 0: that many rounds of parallel insertion-based optimisation of the tree.
 // Blocks until done.
 DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
                                         uint32_t n, uint32_t link_encoding, DeviceBuffer &scratch,
                                         const int32_t *d_mat_ids, float4 *d_nodes,
                                         float4 *d_wnodes, float4 *d_wtris, float4 *d_stris,
-                                        int ploc_radius);
+                                        int ploc_radius, int optimize_passes);
 
 } // namespace mipt

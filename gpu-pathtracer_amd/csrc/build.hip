@@ -470,6 +470,283 @@ __global__ __launch_bounds__(kB) void k_ploc_emit(PlocEmitArgs a) {
     w[3] = make_float4(__int_as_float(ref_l), __int_as_float(ref_r), 0.f, 0.f);
 }
 
+
+// ---- insertion-based optimisation of the finished tree, in parallel ---------------------------
+// After Meister & Bittner 2018 ("Parallel reinsertion for bounding volume hierarchy
+// optimization").  Works on the node numbering of the clustering above (leaves 0..n-1, inner
+// nodes n..2n-2) with parent links.  One pass:
+//   search  every node x looks, from the root down, for the node y next to which it would add
+//           the least surface area (area of y+x, plus what y's ancestors grow by), pruning with
+//           the best found so far; it wants to move if that beats what it costs where it is
+//           (the area of its parent);
+//   bid     a move rewires x, its parent p, its sibling, p's parent, y and y's parent.  In each
+//           of a few rounds the nodes still in the running bid (round, gain, x) for their six
+//           with an atomic max; whoever holds all six has won and keeps them for the rest of
+//           the pass, and whoever finds one of its six kept by a winner drops out, which frees
+//           the others it had outbid for the next round;
+//   accept  winners hold disjoint nodes; one more check keeps subtrees from moving into each
+//           other (see k_u_accept);
+//   apply   rewires.
+// Boxes, depths and the level lists are recomputed between passes.  Every step is
+// deterministic (max is order independent), and nothing is handed between threads of a launch.
+constexpr int kUMaxDepth = 256;
+constexpr int kURounds = 4;          // bidding rounds of a pass (at most 15: four bits of the bid)
+
+struct UTree {
+    PlocNodes t;
+    int32_t *parent;
+    uint32_t n;          // leaves
+    uint32_t total;      // 2n-1
+    int32_t root;
+};
+
+__device__ __forceinline__ float box_area(const float4 lo, const float4 hi) {
+    const float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
+    return (ex * ey + ex * ez) + ey * ez;
+}
+__device__ __forceinline__ float union_area(const float4 alo, const float4 ahi, const float4 blo,
+                                            const float4 bhi) {
+    const float ex = fmaxf(ahi.x, bhi.x) - fminf(alo.x, blo.x);
+    const float ey = fmaxf(ahi.y, bhi.y) - fminf(alo.y, blo.y);
+    const float ez = fmaxf(ahi.z, bhi.z) - fminf(alo.z, blo.z);
+    return (ex * ey + ex * ez) + ey * ez;
+}
+
+// The radix tree in the common numbering: inner node i becomes n + i, leaf position l stays l.
+__global__ __launch_bounds__(kB) void k_u_from_radix(uint32_t n, const int32_t *left,
+                                                     const int32_t *right, const uint32_t *vals,
+                                                     const float4 *boxes, const float4 *ibox,
+                                                     PlocNodes t) {
+    const uint32_t id = blockIdx.x * kB + threadIdx.x;
+    if (id >= 2 * n - 1) return;
+    if (id < n) {
+        const uint32_t tri = vals[id];
+        t.box[2 * (size_t)id + 0] = boxes[2 * (size_t)tri + 0];
+        t.box[2 * (size_t)id + 1] = boxes[2 * (size_t)tri + 1];
+        t.size[id] = 1;
+        return;
+    }
+    const uint32_t i = id - n;
+    t.box[2 * (size_t)id + 0] = ibox[2 * (size_t)i + 0];
+    t.box[2 * (size_t)id + 1] = ibox[2 * (size_t)i + 1];
+    const int32_t l = left[i], r = right[i];
+    t.left[id] = l >= 0 ? (int32_t)n + l : ~l;
+    t.right[id] = r >= 0 ? (int32_t)n + r : ~r;
+}
+
+__global__ __launch_bounds__(kB) void k_u_parents(UTree u) {
+    const uint32_t id = u.n + blockIdx.x * kB + threadIdx.x;
+    if (id >= u.total) return;
+    u.parent[u.t.left[id]] = (int32_t)id;
+    u.parent[u.t.right[id]] = (int32_t)id;
+}
+
+// depth of every node (root 0), the identity list to sort by it, and the level histogram;
+// flag[0] is set if a node lies deeper than the level lists reach
+__global__ __launch_bounds__(kB) void k_u_depth(UTree u, uint32_t *depth, uint32_t *ids,
+                                                unsigned int *histogram, unsigned int *flag) {
+    __shared__ unsigned int s_hist[kUMaxDepth];
+    for (int k = threadIdx.x; k < kUMaxDepth; k += kB) s_hist[k] = 0;
+    __syncthreads();
+    const uint32_t id = blockIdx.x * kB + threadIdx.x;
+    if (id < u.total) {
+        uint32_t d = 0;
+        for (int32_t cur = (int32_t)id; cur != u.root && d < 4u * kUMaxDepth; cur = u.parent[cur]) ++d;
+        if (d >= (uint32_t)kUMaxDepth) {
+            atomicOr(flag, 1u);
+            d = kUMaxDepth - 1;
+        }
+        depth[id] = d;
+        ids[id] = id;
+        atomicAdd(&s_hist[d], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kUMaxDepth; k += kB)
+        if (s_hist[k]) atomicAdd(&histogram[k], s_hist[k]);
+}
+
+// boxes and leaf counts of the inner nodes of one level (their children, one level down, are done)
+__global__ __launch_bounds__(kB) void k_u_refit_level(const uint32_t *level_ids, uint32_t count,
+                                                      UTree u) {
+    const uint32_t k = blockIdx.x * kB + threadIdx.x;
+    if (k >= count) return;
+    const uint32_t id = level_ids[k];
+    if (id < u.n) return;
+    const uint32_t l = (uint32_t)u.t.left[id], r = (uint32_t)u.t.right[id];
+    const float4 llo = u.t.box[2 * (size_t)l], lhi = u.t.box[2 * (size_t)l + 1];
+    const float4 rlo = u.t.box[2 * (size_t)r], rhi = u.t.box[2 * (size_t)r + 1];
+    u.t.box[2 * (size_t)id + 0] = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), 0.f);
+    u.t.box[2 * (size_t)id + 1] = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.f);
+    u.t.size[id] = u.t.size[l] + u.t.size[r];
+}
+
+// pre-order positions of the children of one level's inner nodes (shallowest level first)
+__global__ __launch_bounds__(kB) void k_u_place_level(const uint32_t *level_ids, uint32_t count,
+                                                      UTree u) {
+    const uint32_t k = blockIdx.x * kB + threadIdx.x;
+    if (k >= count) return;
+    const uint32_t id = level_ids[k];
+    if (id < u.n) return;
+    const uint32_t p = u.t.pos[id], b = u.t.before[id];
+    const uint32_t l = (uint32_t)u.t.left[id], r = (uint32_t)u.t.right[id];
+    u.t.pos[l] = p + 1;
+    u.t.before[l] = b;
+    u.t.pos[r] = p + 2 * u.t.size[l];
+    u.t.before[r] = b + u.t.size[l];
+}
+
+__global__ __launch_bounds__(kB) void k_u_search(UTree u, int32_t *target, float *gain,
+                                                 uint32_t *state) {
+    const uint32_t x = blockIdx.x * kB + threadIdx.x;
+    if (x >= u.total) return;
+    target[x] = -1;
+    state[x] = 0;
+    if ((int32_t)x == u.root) return;
+    const int32_t p = u.parent[x];
+    if (p == u.root) return;                       // the root's children stay where they are
+    const float4 xlo = u.t.box[2 * (size_t)x], xhi = u.t.box[2 * (size_t)x + 1];
+    const float ax = box_area(xlo, xhi);
+    const float here = box_area(u.t.box[2 * (size_t)p], u.t.box[2 * (size_t)p + 1]);
+    float best = here;
+    int32_t best_y = -1;
+    constexpr int kStack = 64;
+    int32_t st_node[kStack];
+    float st_ind[kStack];
+    int sp = 0;
+    {   // the root cannot be chosen (nothing is put above it); start with its children
+        st_node[0] = u.t.right[u.root]; st_ind[0] = 0.f;
+        st_node[1] = u.t.left[u.root];  st_ind[1] = 0.f;
+        // what the root grows by if x goes below it: nothing, x is inside it already
+        sp = 2;
+    }
+    int visited = 0;
+    while (sp > 0 && visited < 4096) {
+        --sp;
+        const int32_t y = st_node[sp];
+        const float ind = st_ind[sp];
+        if (ind + ax >= best || y == (int32_t)x) continue;
+        ++visited;
+        const float4 ylo = u.t.box[2 * (size_t)y], yhi = u.t.box[2 * (size_t)y + 1];
+        const float direct = union_area(ylo, yhi, xlo, xhi);
+        const float total = ind + direct;
+        if (total < best && y != p) {
+            best = total;
+            best_y = y;
+        }
+        if ((uint32_t)y >= u.n) {
+            const float down = ind + (direct - box_area(ylo, yhi));
+            if (down + ax < best && sp + 2 <= kStack) {
+                // the child whose box grows less by x is looked at first
+                const int32_t l = u.t.left[y], r = u.t.right[y];
+                const float gl = union_area(u.t.box[2 * (size_t)l], u.t.box[2 * (size_t)l + 1], xlo, xhi);
+                const float gr = union_area(u.t.box[2 * (size_t)r], u.t.box[2 * (size_t)r + 1], xlo, xhi);
+                const bool left_first = gl <= gr;
+                st_node[sp] = left_first ? r : l; st_ind[sp] = down; ++sp;
+                st_node[sp] = left_first ? l : r; st_ind[sp] = down; ++sp;
+            }
+        }
+    }
+    if (best_y >= 0 && best < here * 0.9999f) {
+        target[x] = best_y;
+        gain[x] = here - best;
+        state[x] = 1;
+    }
+}
+
+// the six nodes a move of x next to y rewires; f(node) is called on each and stops the walk
+// by returning false
+template <class F>
+__device__ __forceinline__ bool for_each_rewired(const UTree &u, int32_t x, int32_t y, F f) {
+    const int32_t p = u.parent[x], g = u.parent[p], yp = u.parent[y];
+    const int32_t s = u.t.left[p] == x ? u.t.right[p] : u.t.left[p];
+    return f(x) && f(p) && f(s) && f(g) && f(y) && f(yp);
+}
+
+// (round, gain, x): later rounds outbid what earlier ones left behind; gain > 0, so its bits order
+// like the number (the top 29 of 31 are kept), and x fits 31 bits
+constexpr unsigned long long kTaken = ~0ull;
+__device__ __forceinline__ unsigned long long bid_key(float gain, uint32_t x, int round = 0) {
+    return ((unsigned long long)round << 60) | ((unsigned long long)(__float_as_uint(gain) >> 2) << 31) | x;
+}
+enum : uint32_t { kStill = 0, kBidding = 1, kLost = 2, kWon = 3, kSettled = 4 };
+
+__global__ __launch_bounds__(kB) void k_u_lock(UTree u, const int32_t *target, const float *gain,
+                                               uint32_t *state, int round,
+                                               unsigned long long *lock) {
+    const uint32_t x = blockIdx.x * kB + threadIdx.x;
+    if (x >= u.total || state[x] != kBidding) return;
+    // out, if an earlier round's winner has taken one of the six (taken marks do not change here)
+    if (!for_each_rewired(u, (int32_t)x, target[x], [&](int32_t node) { return lock[node] != kTaken; })) {
+        state[x] = kLost;
+        return;
+    }
+    const unsigned long long key = bid_key(gain[x], x, round);
+    for_each_rewired(u, (int32_t)x, target[x], [&](int32_t node) {
+        atomicMax(&lock[node], key);
+        return true;
+    });
+}
+
+// a bidder that holds all six has won this round
+__global__ __launch_bounds__(kB) void k_u_verify(UTree u, const int32_t *target, const float *gain,
+                                                 const unsigned long long *lock, int round,
+                                                 uint32_t *state) {
+    const uint32_t x = blockIdx.x * kB + threadIdx.x;
+    if (x >= u.total || state[x] != kBidding) return;
+    const unsigned long long key = bid_key(gain[x], x, round);
+    if (for_each_rewired(u, (int32_t)x, target[x], [&](int32_t node) { return lock[node] == key; }))
+        state[x] = kWon;
+}
+
+// the round's winners keep their nodes for the rest of the pass
+__global__ __launch_bounds__(kB) void k_u_settle(UTree u, const int32_t *target, uint32_t *state,
+                                                 unsigned long long *lock) {
+    const uint32_t x = blockIdx.x * kB + threadIdx.x;
+    if (x >= u.total || state[x] != kWon) return;
+    for_each_rewired(u, (int32_t)x, target[x], [&](int32_t node) {
+        lock[node] = kTaken;
+        return true;
+    });
+    state[x] = kSettled;
+}
+
+// Winners hold disjoint nodes, but subtrees moving into each other would still close a cycle
+// (x1 goes below x2 while x2 goes below x1, or round a longer ring).  Every move of such a ring
+// has another one's moving node above its target, so the one with the lowest bid of the ring
+// sees a higher one there and gives way.
+__global__ __launch_bounds__(kB) void k_u_accept(UTree u, const int32_t *target, const float *gain,
+                                                 const uint32_t *state, uint32_t *accepted,
+                                                 unsigned int *moved) {
+    const uint32_t x = blockIdx.x * kB + threadIdx.x;
+    if (x >= u.total) return;
+    accepted[x] = 0;
+    if (state[x] != kSettled) return;
+    const unsigned long long key = bid_key(gain[x], x);
+    for (int32_t a = u.parent[target[x]]; a >= 0; a = u.parent[a])
+        if (state[a] == kSettled && bid_key(gain[a], (uint32_t)a) > key) return;
+    accepted[x] = 1;
+    atomicAdd(moved, 1u);
+}
+
+__global__ __launch_bounds__(kB) void k_u_apply(UTree u, const int32_t *target,
+                                                const uint32_t *accepted) {
+    const uint32_t xi = blockIdx.x * kB + threadIdx.x;
+    if (xi >= u.total || !accepted[xi]) return;
+    const int32_t x = (int32_t)xi, y = target[xi];
+    const int32_t p = u.parent[x], g = u.parent[p];
+    const int32_t s = u.t.left[p] == x ? u.t.right[p] : u.t.left[p];
+    // take p (with x) out: the sibling moves up
+    if (u.t.left[g] == p) u.t.left[g] = s; else u.t.right[g] = s;
+    u.parent[s] = g;
+    // hang p where y was, with y and x below it
+    const int32_t yp = u.parent[y];
+    if (u.t.left[yp] == y) u.t.left[yp] = p; else u.t.right[yp] = p;
+    u.parent[p] = yp;
+    u.t.left[p] = y;
+    u.t.right[p] = x;
+    u.parent[y] = p;
+}
+
 inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kB - 1) / kB); }
 
 #define BUILD_CHECK(expr)                                 \
@@ -488,7 +765,7 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
                                         uint32_t n, uint32_t enc, DeviceBuffer &scratch,
                                         const int32_t *d_mat_ids, float4 *d_nodes,
                                         float4 *d_wnodes, float4 *d_wtris, float4 *d_stris,
-                                        int ploc_radius) {
+                                        int ploc_radius, int optimize_passes) {
     DeviceBuildResult res;
     const uint32_t n_inner = n - 1;
     // scratch carve-up
@@ -507,7 +784,7 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
     const size_t o_depth = take(4 * (size_t)n), o_depth2 = take(4 * (size_t)n);
     const size_t o_lt = take(4 * (size_t)n);
     const size_t o_ids = take(4 * (size_t)n), o_ids2 = take(4 * (size_t)n);
-    const size_t o_small = take(4 * (kMaxDepth + 16));
+    const size_t o_small = take(4 * (kMaxDepth + 16 + kUMaxDepth + 8));
     size_t sort_bytes = 0, sort2_bytes = 0;
     BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long *)nullptr,
                                                    (unsigned long long *)nullptr, (uint32_t *)nullptr,
@@ -519,14 +796,28 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
     BUILD_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr,
                                                  (uint32_t *)nullptr, (int)n, st));
     const size_t o_sort = take(std::max(std::max(sort_bytes, sort2_bytes), scan_bytes));
-    // clustering only: node arrays for 2n-1 nodes (the other arrays above are reused)
+    // clustering and optimisation: node arrays for 2n-1 nodes (the other arrays above are reused)
     const size_t total_nodes = 2 * (size_t)n - 1;
-    const size_t o_pbox = ploc_radius > 0 ? take(32 * total_nodes) : 0;
-    const size_t o_pleft = ploc_radius > 0 ? take(4 * total_nodes) : 0;
-    const size_t o_pright = ploc_radius > 0 ? take(4 * total_nodes) : 0;
-    const size_t o_psize = ploc_radius > 0 ? take(4 * total_nodes) : 0;
-    const size_t o_ppos = ploc_radius > 0 ? take(4 * total_nodes) : 0;
-    const size_t o_pbefore = ploc_radius > 0 ? take(4 * total_nodes) : 0;
+    const bool unified = ploc_radius > 0 || optimize_passes > 0;
+    const size_t o_pbox = unified ? take(32 * total_nodes) : 0;
+    const size_t o_pleft = unified ? take(4 * total_nodes) : 0;
+    const size_t o_pright = unified ? take(4 * total_nodes) : 0;
+    const size_t o_psize = unified ? take(4 * total_nodes) : 0;
+    const size_t o_ppos = unified ? take(4 * total_nodes) : 0;
+    const size_t o_pbefore = unified ? take(4 * total_nodes) : 0;
+    // optimisation only
+    const bool opt = optimize_passes > 0;
+    const size_t o_uparent = opt ? take(4 * total_nodes) : 0;
+    const size_t o_udepth = opt ? take(4 * total_nodes) : 0, o_udepth2 = opt ? take(4 * total_nodes) : 0;
+    const size_t o_uids = opt ? take(4 * total_nodes) : 0, o_uids2 = opt ? take(4 * total_nodes) : 0;
+    const size_t o_utarget = opt ? take(4 * total_nodes) : 0, o_ugain = opt ? take(4 * total_nodes) : 0;
+    const size_t o_ulock = opt ? take(8 * total_nodes) : 0;
+    size_t usort_bytes = 0;
+    if (opt)
+        BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, usort_bytes, (uint32_t *)nullptr,
+                                                       (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                                       (uint32_t *)nullptr, (int)total_nodes, 0, 8, st));
+    const size_t o_usort = opt ? take(usort_bytes) : 0;
     if (scratch.reserve(off) != PT_OK) {
         res.no_memory = true;
         return res;
@@ -544,6 +835,105 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
     unsigned int *small = (unsigned int *)(base + o_small);       // [0..6] bounds, [16..] histogram
     unsigned int *histogram = small + 16;
 
+    // Optimisation passes over the tree in the common numbering, then positions and output.
+    auto optimise_and_emit = [&](PlocNodes t, int32_t root) -> DeviceBuildResult {
+        UTree u;
+        u.t = t;
+        u.parent = (int32_t *)(base + o_uparent);
+        u.n = n;
+        u.total = (uint32_t)total_nodes;
+        u.root = root;
+        uint32_t *udepth = (uint32_t *)(base + o_udepth), *udepth2 = (uint32_t *)(base + o_udepth2);
+        uint32_t *uids = (uint32_t *)(base + o_uids), *uids2 = (uint32_t *)(base + o_uids2);
+        int32_t *target = (int32_t *)(base + o_utarget);
+        float *gain = (float *)(base + o_ugain);
+        unsigned long long *lock = (unsigned long long *)(base + o_ulock);
+        unsigned int *uhist = small + 16 + kMaxDepth, *uflags = uhist + kUMaxDepth;   // [0] too deep, [1] moves
+        const unsigned int g_all = grid_for(total_nodes);
+        const int32_t minus1 = -1;
+        BUILD_CHECK(hipMemcpyAsync(u.parent + root, &minus1, 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_u_parents, dim3(grid_for(n_inner)), dim3(kB), 0, st, u);
+        std::vector<uint32_t> begin(kUMaxDepth + 1, 0);
+        int deepest = 0;
+        // depths, level lists, then boxes and leaf counts bottom-up
+        auto levels_and_refit = [&]() -> hipError_t {
+            hipError_t e = hipMemsetAsync(uhist, 0, 4 * (kUMaxDepth + 8), st);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_u_depth, dim3(g_all), dim3(kB), 0, st, u, udepth, uids, uhist, uflags);
+            e = hipcub::DeviceRadixSort::SortPairs(base + o_usort, usort_bytes, udepth, udepth2, uids, uids2,
+                                                   (int)total_nodes, 0, 8, st);
+            if (e != hipSuccess) return e;
+            unsigned int h[kUMaxDepth + 8];
+            e = hipMemcpyAsync(h, uhist, sizeof(h), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+            if (h[kUMaxDepth]) return hipErrorInvalidValue;        // deeper than the level lists
+            deepest = 0;
+            for (int d = 0; d < kUMaxDepth; ++d) {
+                begin[d + 1] = begin[d] + h[d];
+                if (h[d]) deepest = d;
+            }
+            for (int d = deepest; d >= 0; --d) {
+                const uint32_t cnt = begin[d + 1] - begin[d];
+                if (cnt)
+                    hipLaunchKernelGGL(k_u_refit_level, dim3(grid_for(cnt)), dim3(kB), 0, st,
+                                       uids2 + begin[d], cnt, u);
+            }
+            return hipGetLastError();
+        };
+        for (int pass = 0; pass < optimize_passes; ++pass) {
+            const hipError_t e = levels_and_refit();
+            if (e == hipErrorInvalidValue) break;                  // keep the tree as it is now
+            BUILD_CHECK(e);
+            hipLaunchKernelGGL(k_u_search, dim3(g_all), dim3(kB), 0, st, u, target, gain, udepth2);
+            BUILD_CHECK(hipMemsetAsync(lock, 0, 8 * total_nodes, st));
+            for (int round = 0; round < kURounds; ++round) {
+                hipLaunchKernelGGL(k_u_lock, dim3(g_all), dim3(kB), 0, st, u, target, gain, udepth2, round, lock);
+                hipLaunchKernelGGL(k_u_verify, dim3(g_all), dim3(kB), 0, st, u, target, gain, lock, round, udepth2);
+                hipLaunchKernelGGL(k_u_settle, dim3(g_all), dim3(kB), 0, st, u, target, udepth2, lock);
+            }
+            hipLaunchKernelGGL(k_u_accept, dim3(g_all), dim3(kB), 0, st, u, target, gain, udepth2, udepth,
+                               uflags + 1);
+            hipLaunchKernelGGL(k_u_apply, dim3(g_all), dim3(kB), 0, st, u, target, udepth);
+        }
+        {
+            const hipError_t e = levels_and_refit();
+            if (e == hipErrorInvalidValue) {
+                res.hip_error = e;
+                res.what = "optimised tree deeper than 255 levels";
+                return res;
+            }
+            BUILD_CHECK(e);
+        }
+        const uint32_t zero = 0;
+        BUILD_CHECK(hipMemcpyAsync(t.pos + root, &zero, 4, hipMemcpyHostToDevice, st));
+        BUILD_CHECK(hipMemcpyAsync(t.before + root, &zero, 4, hipMemcpyHostToDevice, st));
+        for (int d = 0; d <= deepest; ++d) {
+            const uint32_t cnt = begin[d + 1] - begin[d];
+            if (cnt)
+                hipLaunchKernelGGL(k_u_place_level, dim3(grid_for(cnt)), dim3(kB), 0, st, uids2 + begin[d],
+                                   cnt, u);
+        }
+        PlocEmitArgs ea;
+        ea.t = t; ea.vals = v1; ea.vtx = d_vtx; ea.idx = d_idx; ea.mat_ids = d_mat_ids;
+        ea.nodes = d_nodes; ea.wnodes = d_wnodes; ea.wtris = d_wtris; ea.stris = d_stris;
+        ea.n = n; ea.enc = enc;
+        hipLaunchKernelGGL(k_ploc_emit, dim3(g_all), dim3(kB), 0, st, ea);
+        BUILD_CHECK(hipGetLastError());
+        BUILD_CHECK(hipStreamSynchronize(st));
+        res.max_depth = (uint32_t)deepest + 1;
+        return res;
+    };
+    PlocNodes unified_nodes{};
+    if (unified) {
+        unified_nodes.box = (float4 *)(base + o_pbox);
+        unified_nodes.left = (int32_t *)(base + o_pleft);
+        unified_nodes.right = (int32_t *)(base + o_pright);
+        unified_nodes.size = (uint32_t *)(base + o_psize);
+        unified_nodes.pos = (uint32_t *)(base + o_ppos);
+        unified_nodes.before = (uint32_t *)(base + o_pbefore);
+    }
+
     // 1. boxes + centre bounds
     {
         unsigned int init[7] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u};
@@ -557,13 +947,7 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
     BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_sort, sort_bytes, k0, k1, v0, v1, (int)n, 0,
                                                    63, st));
     if (ploc_radius > 0) {
-        PlocNodes t;
-        t.box = (float4 *)(base + o_pbox);
-        t.left = (int32_t *)(base + o_pleft);
-        t.right = (int32_t *)(base + o_pright);
-        t.size = (uint32_t *)(base + o_psize);
-        t.pos = (uint32_t *)(base + o_ppos);
-        t.before = (uint32_t *)(base + o_pbefore);
+        PlocNodes t = unified_nodes;
         // the radix-tree arrays double as cluster lists, flags and scans
         uint32_t *cl = (uint32_t *)left, *cl_next = (uint32_t *)right, *nearest = first;
         uint32_t *merge = last, *keep = iparent, *merge_idx = lparent, *new_pos = depth;
@@ -602,6 +986,7 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
         }
         // root = the last node made; place everything top-down, then write the outputs
         const uint32_t root = next_id - 1;
+        if (opt) return optimise_and_emit(t, (int32_t)root);
         const uint32_t zero2[2] = {0u, 0u};
         BUILD_CHECK(hipMemcpyAsync(t.pos + root, &zero2[0], 4, hipMemcpyHostToDevice, st));
         BUILD_CHECK(hipMemcpyAsync(t.before + root, &zero2[1], 4, hipMemcpyHostToDevice, st));
@@ -642,6 +1027,11 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
         max_depth = std::max(max_depth, d);
         hipLaunchKernelGGL(k_refit_level, dim3(grid_for(cnt)), dim3(kB), 0, st, ids2 + begin[d], cnt,
                            left, right, v1, boxes, ibox);
+    }
+    if (opt) {
+        hipLaunchKernelGGL(k_u_from_radix, dim3(grid_for(total_nodes)), dim3(kB), 0, st, n, left, right, v1,
+                           boxes, ibox, unified_nodes);
+        return optimise_and_emit(unified_nodes, (int32_t)n);      // inner node 0, the radix tree's root
     }
     // 6. output
     EmitArgs a;

@@ -198,7 +198,14 @@ int pt_context_set_kernel_timing(pt_context *ctx, int on);
  * 256 MB Infinity Cache and the call has at least 2^18 rays).  Results do not depend on any
  * of them.  "build.ploc_radius" 0..64 selects pt_scene_build's tree: 0 (default) a binary radix
  * tree over the Morton codes, r > 0 locally-ordered clustering with search radius r (lower
- * SAH cost, a few times the build time; it changes the tree, not any hit). */
+ * SAH cost, a few times the build time; it changes the tree, not any hit).
+ * "build.optimize_passes" 0..32 (default 0): passes of parallel insertion-based optimisation
+ * over pt_scene_build's tree (and over the meshes pt_scene_create_instanced builds): every
+ * node looks for the place where it would add the least surface area, and the moves that do
+ * not touch each other's nodes are made.  About 1.5 ms per pass and million triangles; 16
+ * passes bring the radix tree of a million-triangle scene from 75 % to 96 % of the host SAH
+ * tree's closest-hit rate.  Deterministic; the build fails with PT_ERR_HIP if the optimised
+ * tree is deeper than 255 levels. */
 int pt_context_set_option(pt_context *ctx, const char *key, const char *value);
 int pt_context_destroy(pt_context *ctx);
 
@@ -214,7 +221,7 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
  * boxes (:162-172), their inflation (src/bvh/bvh_builder.cpp:53-59, bit-identical to the host
  * path), a linear BVH over the Morton-ordered box centres, the skip-link array in the format
  * of src/bvh/bvh_builder.h:26-34 and the traversal layouts (option "build.ploc_radius"
- * selects clustering instead of the radix tree).  Two orders of magnitude faster
+ * selects clustering instead of the radix tree, "build.optimize_passes" improves either).  Two orders of magnitude faster
  * than pt_bvh_build + pt_scene_create on large meshes; the tree is of lower quality than the
  * SAH builder's (more boxes per ray).  The result is deterministic. */
 int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int32_t *idx,

@@ -13,12 +13,17 @@ from conftest import random_rays, same_hits
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 8, 2], ids=["radix_tree", "clustering", "clustering_r2"], autouse=True)
+@pytest.fixture(params=[(0, 0), (8, 0), (2, 0), (0, 3), (8, 2)],
+                ids=["radix_tree", "clustering", "clustering_r2", "radix_tree_optimised",
+                     "clustering_optimised"], autouse=True)
 def algorithm(request, gpu_ctx):
-    """Both GPU builders: the Morton radix tree (the default) and locally-ordered clustering."""
-    gpu_ctx.set_option("build.ploc_radius", request.param)
+    """The GPU builders: the Morton radix tree (the default) and locally-ordered clustering,
+    each also followed by rounds of parallel insertion-based optimisation."""
+    gpu_ctx.set_option("build.ploc_radius", request.param[0])
+    gpu_ctx.set_option("build.optimize_passes", request.param[1])
     yield request.param
     gpu_ctx.set_option("build.ploc_radius", 0)
+    gpu_ctx.set_option("build.optimize_passes", 0)
 
 
 def _check_tree(mipt, oracle, nodes, vtx, idx, enc):
@@ -118,3 +123,31 @@ def test_device_build_renders_like_the_oracle(mipt, oracle, scenes, gpu_ctx):
     finally:
         film.close()
         sc.close()
+
+
+def test_optimisation_passes_improve_the_tree(mipt, scenes, gpu_ctx, algorithm):
+    """build.optimize_passes: fewer box tests per ray on the same rays with the same hits, and
+    every pass count gives a valid tree (moves of one pass must not collide)."""
+    if algorithm != (0, 0):
+        pytest.skip("sets the options itself")
+    vtx, idx, _, _ = scenes.clutter(200_000, seed=5)
+    rays = scenes.surface_rays(vtx, idx, 1 << 16, seed=3).astype(mipt.ray_dtype)
+    boxes, hits = [], []
+    try:
+        for passes in (0, 1, 6):
+            gpu_ctx.set_option("build.optimize_passes", passes)
+            sc = mipt.Scene(gpu_ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
+            try:
+                mipt.validate_bvh(sc.read_nodes(), idx.shape[0], mipt.PT_LINKS_INT_BITS)
+                got, st = sc.trace_closest(rays, stats=True)
+                boxes.append(st.box_tests / rays.shape[0])
+                hits.append(got)
+            finally:
+                sc.close()
+    finally:
+        gpu_ctx.set_option("build.optimize_passes", 0)
+    assert boxes[1] < boxes[0] and boxes[2] < 0.92 * boxes[0], boxes
+    for h in hits[1:]:
+        # the nearest distance does not depend on the tree; which of two triangles at one distance
+        # is reported may
+        np.testing.assert_array_equal(h["uvwt"][:, 3], hits[0]["uvwt"][:, 3])

@@ -30,11 +30,17 @@ def measure(sc, label):
                       "retraced_rays": int(st.tie_rays)}), flush=True)
 
 
+passes_list = [int(x) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0"])]
 for r in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "8"])]:
-    ctx.set_option("build.ploc_radius", r)
-    sc = mipt.Scene(ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
-    measure(sc, "gpu radix tree" if r == 0 else f"gpu clustering r={r}")
-    sc.close()
+    for passes in passes_list:
+        ctx.set_option("build.ploc_radius", r)
+        ctx.set_option("build.optimize_passes", passes)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        sc = mipt.Scene(ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
+        dt = time.perf_counter() - t0
+        measure(sc, ("gpu radix tree" if r == 0 else f"gpu clustering r={r}") + f", {passes} optimisation passes, built in {dt * 1e3:.0f} ms")
+        sc.close()
 nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah", "mipt.link_encoding": "int"}))
 sc = mipt.Scene(ctx, nodes, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
 measure(sc, "host SAH")
