@@ -2,7 +2,8 @@
 // waves, three ways.  A: each lane loads its own record with four 16-byte loads.  B: the
 // four lanes of a quad load one record per instruction (16 bytes each), no exchange (the
 // ceiling of what coalescing buys).  C: as B, but straight into LDS (global_load_lds), then
-// each lane reads its own record back with four ds_read_b128.
+// each lane reads its own record back with four ds_read_b128.  D: as A with 32-byte records
+// (two loads per lane, the same number of records: what a node of half the size would buy).
 // build: hipcc -O3 --offload-arch=gfx950 -o gather_nodes gather_nodes.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -39,6 +40,19 @@ __global__ __launch_bounds__(256) void k_b(const uint4 *nodes, uint32_t mask, in
             const uint4 a = nodes[4 * (size_t)src + q];
             v += a.x + a.w;
         }
+        acc += v;
+        idx = mixu(v + i) & mask;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_d(const uint4 *nodes, uint32_t mask, int iters, uint32_t *out) {
+    uint32_t idx = mixu(blockIdx.x * 256 + threadIdx.x) & mask;
+    uint32_t acc = 0;
+    for (int i = 0; i < iters; ++i) {
+        const uint4 *p = nodes + 2 * (size_t)idx;
+        uint4 a = p[0], b = p[1];
+        uint32_t v = a.x + b.y + a.z + b.w;
         acc += v;
         idx = mixu(v + i) & mask;
     }
@@ -83,13 +97,14 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&d_out, blocks * 256 * 4));
     CK(hipMemcpy(d_nodes, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int which = 0; which < 3; ++which) {
+    for (int which = 0; which < 4; ++which) {
         float best = 1e30f;
         for (int rep = 0; rep < 4; ++rep) {
             CK(hipEventRecord(e0));
             if (which == 0) k_a<<<blocks, 256>>>(d_nodes, n_nodes - 1, iters, d_out);
             if (which == 1) k_b<<<blocks, 256>>>(d_nodes, n_nodes - 1, iters, d_out);
             if (which == 2) k_c<<<blocks, 256>>>(d_nodes, n_nodes - 1, iters, d_out);
+            if (which == 3) k_d<<<blocks, 256>>>(d_nodes, n_nodes - 1, iters, d_out);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep && ms < best) best = ms;
@@ -97,7 +112,7 @@ int main(int argc, char **argv) {
         std::vector<uint32_t> o(blocks * 256);
         CK(hipMemcpy(o.data(), d_out, o.size() * 4, hipMemcpyDeviceToHost));
         uint32_t chk = 0; for (auto x : o) chk ^= x;
-        printf("%c: %.3f ms  %.1f G records/s  check %08x\n", "ABC"[which], best,
+        printf("%c: %.3f ms  %.1f G records/s  check %08x\n", "ABCD"[which], best,
                (double)blocks * 256 * iters / best * 1e-6, chk);
     }
     return 0;
