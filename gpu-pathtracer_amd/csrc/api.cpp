@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/mipt.h"
+#include "../../include/pt_config.h"
 #include "../host/bvh.h"
 #include "build.h"
 #include "internal.h"
@@ -267,6 +268,11 @@ int pt_context_create(int device, pt_context **out) {
     ctx->stream = ctx->own_stream;
     HIP_CHECK(hipMalloc((void **)&ctx->counters, sizeof(DeviceTraceCounters)));
     HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(DeviceTraceCounters), ctx->stream));
+    // stack slots in global memory for the few rays that outgrow the LDS stack, for every lane
+    // of the largest persistent grid; without them such rays fall back to the fixed-order walk
+    if (ctx->stack_spill.reserve((size_t)ctx->num_cus * kMaxBlocksPerCu * PT_TRACE_BLOCK *
+                                 kSpillEntries * sizeof(int32_t)) != PT_OK)
+        (void)hipGetLastError();
     *out = ctx.release();
     return PT_OK;
     PT_CATCH

@@ -45,6 +45,7 @@ struct pt_context {
     mipt::DeviceBuffer render_ws;   // wavefront state of pt_render
     mipt::DeviceBuffer sort_scratch;    // keys and order of a sorted trace call
     mipt::DeviceBuffer render_counts;   // queue sizes per pass and bounce
+    mipt::DeviceBuffer stack_spill;     // see ExtendConfig::spill (allocated with the context)
     std::vector<hipEvent_t> events;     // pool for per-kernel timing
 
     mipt::ExtendConfig extend_config() const {
@@ -55,6 +56,8 @@ struct pt_context {
         c.refill = extend_refill;
         c.leaf_lanes = extend_leaf_lanes;
         c.sort_rays = 0;
+        c.spill = (int32_t *)stack_spill.ptr;
+        c.spill_entries = stack_spill.ptr ? mipt::kSpillEntries : 0;
         return c;
     }
 
@@ -66,6 +69,7 @@ struct pt_context {
         io_hits.release();
         render_ws.release();
         sort_scratch.release();
+        stack_spill.release();
         if (counters) (void)hipFree(counters);
         counters = nullptr;
         if (own_stream) (void)hipStreamDestroy(own_stream);

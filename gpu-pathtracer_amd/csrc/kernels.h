@@ -70,7 +70,16 @@ struct ExtendConfig {
     int refill;             // persistent form: top up a wave when this many lanes are idle
     int leaf_lanes;         // persistent form: triangle step once this many lanes wait at one
     int sort_rays;          // trace calls, persistent form: take the rays in origin-cell order
+    // persistent form: global memory for the stack entries of rays that need more than the LDS
+    // holds, spill_entries slots for each lane of the largest grid (kSpillEntries, or 0)
+    int32_t *spill;
+    int spill_entries;
 };
+
+// Stack entries per lane beyond the LDS ones: a ray stays in the voted loop up to about
+// PT_LDS_STACK_ENTRIES + kSpillEntries pending nodes before it is left to the fixed-order walk.
+constexpr int kSpillEntries = 48;
+constexpr int kMaxBlocksPerCu = 8;      // upper end of option "extend.blocks_per_cu"
 
 // Closest hit in the reference's fixed skip-link order.
 void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,

@@ -217,6 +217,22 @@ __device__ __forceinline__ void traverse_ordered(const DeviceScene &s, const flo
 }
 
 // ---- the same traversal as a resumable state machine (persistent-wave kernels) ---------
+// Where a lane's stack goes on once its LDS entries are used up: `entries` more slots in global
+// memory, slot e of all the grid's lanes side by side.  entries == 0: there is none.
+struct StackSpill {
+    int32_t *lane;
+    uint32_t stride;
+    int entries;
+};
+__device__ __forceinline__ StackSpill lane_spill(int32_t *base, int entries) {
+    StackSpill x;
+    x.stride = gridDim.x * kTraceBlock;
+    x.lane = base ? base + (blockIdx.x * kTraceBlock + threadIdx.x) : nullptr;
+    x.entries = base ? entries : 0;
+    return x;
+}
+constexpr int kSpillBlock = 8;      // entries that move between LDS and global memory at a time
+
 struct OrderedState {
     RayPre r;
     float tmax, tbest, bound, second, b0, b1, b2;
@@ -317,11 +333,14 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                 const bool hb = intersect_box(st.r, b.x, b.y, b.z, b.w, c.z, c.w, st.bound, tb);
                 const bool take_b = hb & (!ha | (tb < ta));     // the nearer hit child is c1
                 const bool both = ha & hb, none = !(ha | hb);
-                const bool full = both & (st.sp > kTraceStack);
+                // No room for the farther child: the lane stops here with the node itself on top
+                // of its stack (the last slot is kept for that), and whoever drives the loop
+                // makes room and repeats the step (stack_service) or gives the ray up.
+                const bool full = both & (st.sp >= kTraceStack);
                 int32_t next = take_b ? ch.y : ch.x;
-                if (both & !full) stack[st.sp * kTraceBlock] = take_b ? ch.x : ch.y;
-                st.sp += (both & !full) ? 1 : 0;
-                st.tie |= full;
+                const int32_t far_c = take_b ? ch.x : ch.y;
+                if (both) stack[st.sp * kTraceBlock] = full ? st.cur : far_c;
+                st.sp += both ? 1 : 0;
                 if (none) {
                     --st.sp;
                     next = stack[st.sp * kTraceBlock];
@@ -376,6 +395,42 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
             st.cur = bad ? kSentinel : popped;
         }
     }
+}
+
+// For a lane whose run has stopped (st.cur == kSentinel): true if it goes on.  A run that
+// stopped for lack of stack room (entries left above the sentinel at `base`, no hit that ended
+// an occlusion query, no tie flag) moves its oldest kSpillBlock entries to the lane's global
+// slots, closes the gap and repeats the step of the node it stopped at; a run whose LDS entries
+// have run out while blocks are in global memory brings the newest block back.  `spilled`
+// counts the lane's blocks out there (0 at the start of a run).  Without room out there the
+// run gets its tie flag, i.e. the ray is left to the fixed-order walk.
+template <bool ANY>
+__device__ __forceinline__ bool stack_service(OrderedState &st, int32_t *stack, const StackSpill &x,
+                                              int base, int &spilled) {
+    if (st.tie || (ANY && st.primid >= 0)) return false;
+    if (st.sp > base) {
+        if ((spilled + 1) * kSpillBlock > x.entries) {
+            st.tie = true;
+            return false;
+        }
+        for (int e = 0; e < kSpillBlock; ++e)
+            x.lane[(size_t)(spilled * kSpillBlock + e) * x.stride] = stack[(base + 1 + e) * kTraceBlock];
+        for (int i = base + 1 + kSpillBlock; i < st.sp; ++i)
+            stack[(i - kSpillBlock) * kTraceBlock] = stack[i * kTraceBlock];
+        st.sp -= kSpillBlock + 1;
+        st.cur = stack[st.sp * kTraceBlock];                      // the node that found no room
+        ++spilled;
+        return true;
+    }
+    if (spilled > 0) {
+        --spilled;
+        for (int e = 0; e < kSpillBlock; ++e)
+            stack[(base + 1 + e) * kTraceBlock] = x.lane[(size_t)(spilled * kSpillBlock + e) * x.stride];
+        st.sp = base + kSpillBlock;
+        st.cur = stack[st.sp * kTraceBlock];
+        return true;
+    }
+    return false;
 }
 
 // Call once for a lane whose traversal has ended; true if the ray must be re-resolved.
@@ -650,6 +705,7 @@ template <bool COUNT, bool ANY, class Sink>
 __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const pt_ray *rays,
                                                     uint32_t n, bool fixup, int refill,
                                                     int leaf_lanes, int32_t *stack,
+                                                    const StackSpill spill,
                                                     unsigned int *tie_count,
                                                     DeviceTraceCounters *work, Sink sink,
                                                     const uint32_t *perm = nullptr) {
@@ -674,8 +730,10 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     unsigned long long nb = 0, nt = 0;
     unsigned int n_ties = 0;
     const bool any_exact = s.n_tri < 2;         // see occluded_wide
+    int spilled = 0;                            // blocks of this lane's stack in global memory
     for (;;) {
-        if (my_ray != kNone && st.cur == kSentinel) {          // retire a finished ray
+        if (my_ray != kNone && st.cur == kSentinel &&
+            !stack_service<ANY>(st, stack, spill, 0, spilled)) {   // retire a finished ray
             if constexpr (ANY) {
                 bool occ = st.primid >= 0;
                 if (st.tie) {
@@ -713,6 +771,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                     if constexpr (ANY) any_begin(st, ro, rd, stack, any_exact);
                     else ordered_begin(st, ro, rd, stack);
                     my_ray = ri;
+                    spilled = 0;
                 }
             }
             pos += (uint32_t)__popcll(m);
@@ -754,7 +813,8 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
 template <bool COUNT, bool ANY, class Sink>
 __device__ __forceinline__ void persistent_traverse_two_level(
     const DeviceScene &s, const pt_ray *rays, uint32_t n, bool fixup, int refill, int leaf_lanes,
-    int32_t *stack, unsigned int *tie_count, DeviceTraceCounters *work, Sink sink) {
+    int32_t *stack, const StackSpill spill, unsigned int *tie_count, DeviceTraceCounters *work,
+    Sink sink) {
     const uint32_t lane = threadIdx.x & 63u;
     // readfirstlane: the wave index is the same in all 64 lanes, which the compiler cannot see
     // from threadIdx; with it the stream bookkeeping and the loop control stay scalar
@@ -784,8 +844,10 @@ __device__ __forceinline__ void persistent_traverse_two_level(
     float second = INFINITY, bound = 0.f;
     unsigned long long nb = 0, nt = 0;
     unsigned int n_ties = 0;
+    int spilled = 0;               // blocks of the mesh search's stack in global memory
     for (;;) {
-        if (my_ray != kNone && st.cur == kSentinel) {
+        if (my_ray != kNone && st.cur == kSentinel &&
+            !(cur_inst >= 0 && stack_service<ANY>(st, stack, spill, top_sp, spilled))) {
             const float4 ro = reinterpret_cast<const float4 *>(rays + my_ray)[0];
             const float4 rd = reinterpret_cast<const float4 *>(rays + my_ray)[1];
             bool done = false;
@@ -855,6 +917,7 @@ __device__ __forceinline__ void persistent_traverse_two_level(
                         float4 oo = ro, od = rd;
                         int32_t root;
                         const DeviceScene m = enter_instance(s, cur_inst, oo, od, root);
+                        spilled = 0;
                         if constexpr (ANY) {
                             any_begin(st, oo, od, stack, m.n_tri < 2, root, top_sp);
                         } else {
@@ -942,11 +1005,12 @@ template <bool COUNT>
 __device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, const pt_ray *rays,
                                                         pt_hit *hits, uint32_t n, bool fixup,
                                                         int refill, int leaf_lanes, int32_t *stack,
+                                                        const StackSpill spill,
                                                         unsigned int *tie_count,
                                                         DeviceTraceCounters *work,
                                                         const uint32_t *perm = nullptr) {
-    persistent_traverse<COUNT, false>(s, rays, n, fixup, refill, leaf_lanes, stack, tie_count, work,
-                                      HitSink{hits}, perm);
+    persistent_traverse<COUNT, false>(s, rays, n, fixup, refill, leaf_lanes, stack, spill, tie_count,
+                                      work, HitSink{hits}, perm);
 }
 
 // Compacting append to a queue: every lane with `keep` gets a distinct slot.  One atomic

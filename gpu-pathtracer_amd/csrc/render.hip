@@ -127,10 +127,12 @@ __global__ __launch_bounds__(kBlock) void k_pt_extend_two_level(DeviceScene s, c
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_two_level_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, const unsigned int *count,
-    unsigned int *tie_count, DeviceTraceCounters *work, int refill, int leaf_lanes) {
+    unsigned int *tie_count, DeviceTraceCounters *work, int refill, int leaf_lanes,
+    int32_t *spill, int spill_entries) {
     __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
     persistent_traverse_two_level<COUNT, false>(s, rays, *count, true, refill, leaf_lanes,
-                                                s_stack + threadIdx.x, tie_count, work,
+                                                s_stack + threadIdx.x,
+                                                lane_spill(spill, spill_entries), tie_count, work,
                                                 HitSink{hits});
 }
 
@@ -145,10 +147,11 @@ __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_persi
                                                                 const unsigned int *count,
                                                                 unsigned int *tie_count,
                                                                 DeviceTraceCounters *work,
-                                                                int refill, int leaf_lanes) {
+                                                                int refill, int leaf_lanes,
+                                                                int32_t *spill, int spill_entries) {
     __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];   // + the bottom sentinel
     persistent_closest_hits<COUNT>(s, rays, hits, *count, true, refill, leaf_lanes, s_stack + threadIdx.x,
-                                   tie_count, work);
+                                   lane_spill(spill, spill_entries), tie_count, work);
 }
 
 // shade: one path vertex per queued hit; survivors are appended to the next queue.
@@ -283,19 +286,23 @@ __global__ __launch_bounds__(kBlock) void k_pt_occlude_two_level(DeviceScene s, 
 }
 
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_two_level_persistent(
-    DeviceScene s, RenderWorkspace ws, const unsigned int *count, int refill, int leaf_lanes) {
+    DeviceScene s, RenderWorkspace ws, const unsigned int *count, int refill, int leaf_lanes,
+    int32_t *spill, int spill_entries) {
     __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
     persistent_traverse_two_level<false, true>(s, ws.shadow_rays, *count, true, refill, leaf_lanes,
-                                               s_stack + threadIdx.x, nullptr, nullptr,
+                                               s_stack + threadIdx.x,
+                                               lane_spill(spill, spill_entries), nullptr, nullptr,
                                                ShadowSink{ws.shadow_carry, ws.radiance});
 }
 
 // Persistent waves with lane refill and step voting, as the closest-hit kernel.
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_persistent(
-    DeviceScene s, RenderWorkspace ws, const unsigned int *count, int refill, int leaf_lanes) {
+    DeviceScene s, RenderWorkspace ws, const unsigned int *count, int refill, int leaf_lanes,
+    int32_t *spill, int spill_entries) {
     __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
     persistent_traverse<false, true>(s, ws.shadow_rays, *count, true, refill, leaf_lanes,
-                                     s_stack + threadIdx.x, nullptr, nullptr,
+                                     s_stack + threadIdx.x, lane_spill(spill, spill_entries),
+                                     nullptr, nullptr,
                                      ShadowSink{ws.shadow_carry, ws.radiance});
 }
 
@@ -371,10 +378,12 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
             blocks(max_rays, kBlock), persistent_grid(k, kBlock, cfg, &occ2[work ? 1 : 0]));
         if (work)
             hipLaunchKernelGGL(k_pt_extend_two_level_persistent<true>, dim3(grid), dim3(kBlock), 0, st,
-                               s, ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes);
+                               s, ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes,
+                               cfg.spill, cfg.spill_entries);
         else
             hipLaunchKernelGGL(k_pt_extend_two_level_persistent<false>, dim3(grid), dim3(kBlock), 0, st,
-                               s, ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes);
+                               s, ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes,
+                               cfg.spill, cfg.spill_entries);
         return;
     }
     if (s.tlas) {
@@ -394,10 +403,12 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
             blocks(max_rays, kBlock), persistent_grid(k, kBlock, cfg, &occ[work ? 1 : 0]));
         if (work)
             hipLaunchKernelGGL(k_pt_extend_persistent<true>, dim3(grid), dim3(kBlock), 0, st, s,
-                               ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes);
+                               ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes,
+                               cfg.spill, cfg.spill_entries);
         else
             hipLaunchKernelGGL(k_pt_extend_persistent<false>, dim3(grid), dim3(kBlock), 0, st, s,
-                               ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes);
+                               ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes,
+                               cfg.spill, cfg.spill_entries);
         return;
     }
     if (work)
@@ -427,7 +438,7 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
             blocks(max_rays, kBlock),
             persistent_grid((const void *)k_pt_occlude_two_level_persistent, kBlock, cfg, &occ2));
         hipLaunchKernelGGL(k_pt_occlude_two_level_persistent, dim3(grid), dim3(kBlock), 0, st, s, ws,
-                           shadow_count, cfg.refill, cfg.leaf_lanes);
+                           shadow_count, cfg.refill, cfg.leaf_lanes, cfg.spill, cfg.spill_entries);
         return;
     }
     if (s.tlas) {
@@ -441,7 +452,7 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
             blocks(max_rays, kBlock),
             persistent_grid((const void *)k_pt_occlude_persistent, kBlock, cfg, &occ));
         hipLaunchKernelGGL(k_pt_occlude_persistent, dim3(grid), dim3(kBlock), 0, st, s, ws,
-                           shadow_count, cfg.refill, cfg.leaf_lanes);
+                           shadow_count, cfg.refill, cfg.leaf_lanes, cfg.spill, cfg.spill_entries);
         return;
     }
     hipLaunchKernelGGL(k_pt_occlude, dim3(blocks(max_rays, kBlock)), dim3(kBlock), 0, st, s, ws,

@@ -71,11 +71,13 @@ __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_ordered_p
                                                                     const pt_ray *rays,
                                                                     pt_hit *hits, uint32_t n,
                                                                     bool fixup, int refill, int leaf_lanes,
+                                                                    int32_t *spill, int spill_entries,
                                                                     DeviceTraceCounters *counters,
                                                                     const uint32_t *perm) {
     __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];   // + the bottom sentinel
     persistent_closest_hits<COUNT>(s, rays, hits, n, fixup, refill, leaf_lanes, s_stack + threadIdx.x,
-                                   &counters->tie_count, counters, perm);
+                                   lane_spill(spill, spill_entries), &counters->tie_count, counters,
+                                   perm);
 }
 
 // IntersectSceneAny, shaders/RadeonRays/bvh.glslh:378-414 (leaf test :350-375, :289-310).
@@ -100,10 +102,12 @@ struct OccludedSink {
     }
 };
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_persistent(
-    DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, int refill, int leaf_lanes) {
+    DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, int refill, int leaf_lanes,
+    int32_t *spill, int spill_entries) {
     __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
     persistent_traverse<false, true>(s, rays, n, true, refill, leaf_lanes, s_stack + threadIdx.x,
-                                     nullptr, nullptr, OccludedSink{occluded});
+                                     lane_spill(spill, spill_entries), nullptr, nullptr,
+                                     OccludedSink{occluded});
 }
 
 // Two-level scenes: one thread per ray (see closest_hit_two_level).
@@ -151,17 +155,20 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_two_level(DeviceScene s, c
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_two_level_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, uint32_t n, bool fixup, int refill,
-    int leaf_lanes, DeviceTraceCounters *counters) {
+    int leaf_lanes, int32_t *spill, int spill_entries, DeviceTraceCounters *counters) {
     __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
     persistent_traverse_two_level<COUNT, false>(s, rays, n, fixup, refill, leaf_lanes,
-                                                s_stack + threadIdx.x, &counters->tie_count,
-                                                counters, HitSink{hits});
+                                                s_stack + threadIdx.x,
+                                                lane_spill(spill, spill_entries),
+                                                &counters->tie_count, counters, HitSink{hits});
 }
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_two_level_persistent(
-    DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, int refill, int leaf_lanes) {
+    DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, int refill, int leaf_lanes,
+    int32_t *spill, int spill_entries) {
     __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
     persistent_traverse_two_level<false, true>(s, rays, n, true, refill, leaf_lanes,
-                                               s_stack + threadIdx.x, nullptr, nullptr,
+                                               s_stack + threadIdx.x,
+                                               lane_spill(spill, spill_entries), nullptr, nullptr,
                                                OccludedSink{occluded});
 }
 
@@ -246,10 +253,12 @@ void launch_trace_two_level(hipStream_t st, const DeviceScene &s, const pt_ray *
             grid_for(n), persistent_grid(k, kBlock, cfg, &occ[count_work ? 1 : 0]));
         if (count_work)
             hipLaunchKernelGGL((k_trace_two_level_persistent<true>), dim3(grid), dim3(kBlock), 0, st,
-                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, counters);
+                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, cfg.spill,
+                               cfg.spill_entries, counters);
         else
             hipLaunchKernelGGL((k_trace_two_level_persistent<false>), dim3(grid), dim3(kBlock), 0, st,
-                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, counters);
+                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, cfg.spill,
+                               cfg.spill_entries, counters);
         return;
     }
     if (count_work)
@@ -295,10 +304,12 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
             grid_for(n), persistent_grid(k, kBlock, cfg, &occ[count_work ? 1 : 0]));
         if (count_work)
             hipLaunchKernelGGL((k_trace_ordered_persistent<true>), dim3(grid), dim3(kBlock), 0, st,
-                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, counters, perm);
+                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, cfg.spill,
+                               cfg.spill_entries, counters, perm);
         else
             hipLaunchKernelGGL((k_trace_ordered_persistent<false>), dim3(grid), dim3(kBlock), 0, st,
-                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, counters, perm);
+                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, cfg.spill,
+                               cfg.spill_entries, counters, perm);
         return;
     }
     const unsigned int grid = grid_for(n);
@@ -320,7 +331,8 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
                 grid_for(n),
                 persistent_grid((const void *)k_trace_any_two_level_persistent, kBlock, cfg, &occ2));
             hipLaunchKernelGGL(k_trace_any_two_level_persistent, dim3(grid), dim3(kBlock), 0, st, s,
-                               rays, occluded, (uint32_t)n, cfg.refill, cfg.leaf_lanes);
+                               rays, occluded, (uint32_t)n, cfg.refill, cfg.leaf_lanes, cfg.spill,
+                               cfg.spill_entries);
             return;
         }
         hipLaunchKernelGGL(k_trace_any_two_level, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays,
@@ -333,7 +345,7 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
         const unsigned int grid = (unsigned int)std::min<uint64_t>(
             grid_for(n), persistent_grid((const void *)k_trace_any_persistent, kBlock, cfg, &occ));
         hipLaunchKernelGGL(k_trace_any_persistent, dim3(grid), dim3(kBlock), 0, st, s, rays, occluded,
-                           (uint32_t)n, cfg.refill, cfg.leaf_lanes);
+                           (uint32_t)n, cfg.refill, cfg.leaf_lanes, cfg.spill, cfg.spill_entries);
         return;
     }
     hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays, occluded, n,

@@ -21,9 +21,10 @@
  * whose distances differ by less than this fraction are re-resolved in the
  * reference's fixed skip-link order.  2^-18. */
 #define PT_TIE_WINDOW 3.814697265625e-06f
-/* Per-lane entries of the LDS traversal stack. */
+/* Per-lane entries of the LDS traversal stack: 31 x 4 B x 256 lanes with the sentinel, so that
+ * five workgroups fit the 160 KB of a compute unit. */
 #ifndef PT_LDS_STACK_ENTRIES
-#define PT_LDS_STACK_ENTRIES 24
+#define PT_LDS_STACK_ENTRIES 30
 #endif
 /* Threads per workgroup of the traversal kernels (4 wave64). */
 #define PT_TRACE_BLOCK 256

@@ -206,6 +206,61 @@ def test_deep_tree_overflows_the_lds_stack_safely(mipt, oracle, gpu_ctx):
     _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays)
 
 
+def _comb_tree(oracle, vtx, idx):
+    """A hand-made skip-link tree of depth n: inner node i holds triangle i and inner node i+1
+    (pre-order: inner_0, leaf_0, inner_1, leaf_1, ..., leaf_{n-2}, leaf_{n-1}; float links)."""
+    n = idx.shape[0]
+    leaves = oracle.inflate(oracle.mesh_leaf_bounds(vtx, idx))
+    nodes = np.zeros(2 * n - 1, dtype=leaves.dtype)
+    lo = np.minimum.accumulate(leaves["pmin"][::-1, :3], 0)[::-1]      # box of triangles i..n-1
+    hi = np.maximum.accumulate(leaves["pmax"][::-1, :3], 0)[::-1]
+    for i in range(n - 1):
+        nodes["pmin"][2 * i, :3], nodes["pmax"][2 * i, :3] = lo[i], hi[i]
+        nodes["pmin"][2 * i, 3], nodes["pmax"][2 * i, 3] = -1, -1      # inner; nothing follows its subtree
+        nodes[2 * i + 1] = leaves[i]
+        nodes["pmin"][2 * i + 1, 3], nodes["pmax"][2 * i + 1, 3] = i, 2 * i + 2
+    nodes[2 * n - 2] = leaves[n - 1]
+    nodes["pmin"][2 * n - 2, 3], nodes["pmax"][2 * n - 2, 3] = n - 1, -1
+    return nodes
+
+
+@pytest.mark.parametrize("n", [25, 33, 45, 75, 150])
+def test_stack_goes_on_in_global_memory(mipt, oracle, gpu_ctx, n):
+    """Trees deeper than the LDS stack: a ray that enters the comb from its deep end holds one
+    pending leaf per level.  Up to the room in global memory such rays stay in the voted loop
+    (no re-resolved rays), beyond it they are left to the fixed-order walk; either way the hits
+    are the oracle's, for closest-hit and occlusion queries, with many rays in flight so that
+    lanes spill and reload independently."""
+    x = np.arange(n, dtype=np.float64) * 1.25
+    tri = np.array([[0, -1, -1], [0, 1, -1], [0, 0, 1]], dtype=np.float64) * 0.4
+    vtx = (tri[None] + np.stack([x, 0 * x, 0 * x], 1)[:, None]).reshape(-1, 3).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+    nodes = _comb_tree(oracle, vtx, idx)
+    mipt.validate_bvh(nodes, n, mipt.PT_LINKS_FLOAT_VALUE)
+    rng = np.random.default_rng(n)
+    m = 20000
+    rays = np.zeros(m, dtype=mipt.ray_dtype)
+    # from beyond the last triangle back along the comb, slightly tilted, so that every level's
+    # nearer child is the rest of the comb; a third of them miss everything and unwind the
+    # whole stack; some start in the middle
+    rays["o"][:, 0] = np.where(rng.random(m) < 0.7, x[-1] + 1.0, rng.uniform(0, x[-1], m))
+    rays["o"][:, 1:3] = rng.uniform(-0.45, 0.45, (m, 2))
+    rays["o"][:, 3] = 1e30
+    rays["d"][:, 0] = -1
+    rays["d"][:, 1:3] = rng.uniform(-0.004, 0.004, (m, 2))
+    rays["d"][::3, 1] = rng.uniform(0.01, 0.02, len(rays[::3]))        # grazing: these mostly miss
+    limit = 29 + 48        # pending nodes a lane can hold: LDS entries (one is kept free) + global slots
+    got, st = _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays,
+                               expect_ties=(lambda t: t == 0) if n - 1 <= limit else (lambda t: t > 0))
+    assert (got["primid"] >= 0).mean() > 0.3 and (got["primid"] < 0).mean() > 0.05
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx)
+    try:
+        rays["o"][:, 3] = rng.uniform(0.5, 1.5 * x[-1], m)
+        np.testing.assert_array_equal(sc.trace_any(rays), oracle.any_hit(nodes, vtx, idx, rays, nthreads=8))
+    finally:
+        sc.close()
+
+
 def test_non_finite_rays_follow_the_reference_arithmetic(mipt, oracle, scenes, gpu_ctx):
     """NaN / infinite / zero-direction rays: the shader's arithmetic "accepts" a NaN distance
     on the first triangle it tests and then culls everything, so the answer depends on the

@@ -127,7 +127,8 @@ def lucy(ctx):
 
 
 def gpubuild(ctx):
-    """pt_scene_build (GPU: locally-ordered clustering, or the Morton radix tree) against
+    """pt_scene_build (GPU: locally-ordered clustering, the Morton radix tree, and the radix tree
+    after 8 passes of parallel insertion-based optimisation) against
     pt_bvh_build + pt_scene_create (host SAH):
     time to a traceable scene from host arrays, and the tracing rate each tree gives."""
     out = {"config": "BVH build: GPU linear BVH vs host SAH", "scenes": []}
@@ -140,8 +141,9 @@ def gpubuild(ctx):
         d_h = torch.empty_like(d_r)
         row = {"scene": name, "tris": int(idx.shape[0])}
         hits = {}
-        for kind in ("gpu_ploc", "gpu_lbvh", "host_sah"):
+        for kind in ("gpu_ploc", "gpu_lbvh", "gpu_lbvh_opt8", "host_sah"):
             ctx.set_option("build.ploc_radius", 8 if kind == "gpu_ploc" else 0)
+            ctx.set_option("build.optimize_passes", 8 if kind == "gpu_lbvh_opt8" else 0)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if kind != "host_sah":
@@ -166,8 +168,8 @@ def gpubuild(ctx):
             hits[kind] = d_h.view(torch.int32)[:, 1].clone(), d_h[:, 7].clone()
             sc.close()
         # both trees must find the same nearest distance (ids can differ between exact ties)
-        row["same_t"] = bool(torch.equal(hits["gpu_lbvh"][1], hits["host_sah"][1]) and
-                             torch.equal(hits["gpu_ploc"][1], hits["host_sah"][1]))
+        row["same_t"] = bool(all(torch.equal(hits[k][1], hits["host_sah"][1])
+                                 for k in ("gpu_lbvh", "gpu_ploc", "gpu_lbvh_opt8")))
         row["same_primid_fraction"] = float((hits["gpu_ploc"][0] == hits["host_sah"][0]).float().mean().item())
         out["scenes"].append(row)
         print(json.dumps(row), flush=True)
