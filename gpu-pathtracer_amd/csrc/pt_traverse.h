@@ -58,11 +58,47 @@ __device__ __forceinline__ void traverse_skiplink(const DeviceScene &s, const fl
                                                   const float4 rd, int32_t &shapeid,
                                                   int32_t &primid, float &b0, float &b1, float &b2,
                                                   float &tbest, unsigned long long &nb,
-                                                  unsigned long long &nt) {
+                                                  unsigned long long &nt,
+                                                  float limit = INFINITY) {
     const RayPre r = precompute_ray(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
     b0 = 0.f; b1 = 0.f; b2 = 0.f; tbest = ro.w;           // :423
     shapeid = -1; primid = -1;                              // :424-425
     int32_t idx = 0;
+    // limit: a distance beyond which the caller knows the answer does not lie (the nearest hit
+    // of the ordered traversal, widened by the tie window).  The walk starts culling there
+    // instead of at r.o.w: hits beyond it would be replaced before the walk ends, so skipping
+    // them and the boxes only they need leaves the result as it is.
+    if (!MT && limit < tbest) {
+        float cull = limit;
+        while (idx != -1) {
+            const float4 lo = s.nodes[2 * (int64_t)idx + 0];
+            const float4 hi = s.nodes[2 * (int64_t)idx + 1];
+            if (COUNT) ++nb;
+            float t0;
+            const int32_t link = decode_link(hi.w, s.link_enc);
+            const int32_t payload = decode_link(lo.w, s.link_enc);
+            if (!intersect_box(r, lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, cull, t0)) {
+                idx = link;
+            } else if (payload == -1) {
+                ++idx;
+            } else {
+                if (COUNT) ++nt;
+                const int64_t start = payload;
+                const float *p0 = s.vtx + 3 * (int64_t)s.idx[3 * start + 0];
+                const float *p1 = s.vtx + 3 * (int64_t)s.idx[3 * start + 1];
+                const float *p2 = s.vtx + 3 * (int64_t)s.idx[3 * start + 2];
+                float h0, h1, h2, ht;
+                if (intersect_triangle_watertight(r, p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], p2[0],
+                                                  p2[1], p2[2], cull, h0, h1, h2, ht)) {
+                    b0 = h0; b1 = h1; b2 = h2; tbest = ht; cull = ht;
+                    primid = payload;
+                    shapeid = 0;
+                }
+                idx = link;
+            }
+        }
+        return;
+    }
     while (idx != -1) {
         const float4 lo = s.nodes[2 * (int64_t)idx + 0];
         const float4 hi = s.nodes[2 * (int64_t)idx + 1];
@@ -731,9 +767,39 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     unsigned int n_ties = 0;
     const bool any_exact = s.n_tri < 2;         // see occluded_wide
     int spilled = 0;                            // blocks of this lane's stack in global memory
+    // A ray whose answer may depend on the visiting order is walked again in the reference's
+    // fixed order.  That walk is serial and long, so a lane does not start it on the spot with
+    // the other 63 waiting: it parks the ray here and goes on, and the parked rays of a wave
+    // are walked side by side once kTieBatch of them have gathered, when a lane has a second
+    // one to park, and at the end of the wave's stream.
+    constexpr int kTieBatch = PT_TIE_BATCH;
+    uint32_t parked = kNone, parked2 = kNone;   // two places per lane: batches get larger
+    float parked_limit = INFINITY, parked2_limit = INFINITY;   // see traverse_skiplink
+    auto walk_parked = [&]() {
+        while (parked != kNone) {
+            int32_t shapeid, primid;
+            float b0, b1, b2, t;
+            unsigned long long xb = 0, xt = 0;
+            const float4 ro = reinterpret_cast<const float4 *>(rays + parked)[0];
+            const float4 rd = reinterpret_cast<const float4 *>(rays + parked)[1];
+            traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt,
+                                            parked_limit);
+            if constexpr (!ANY) sink(parked, shapeid, primid, b0, b1, b2, t);
+            parked = parked2;
+            parked_limit = parked2_limit;
+            parked2 = kNone;
+        }
+    };
     for (;;) {
-        if (my_ray != kNone && st.cur == kSentinel &&
-            !stack_service<ANY>(st, stack, spill, 0, spilled)) {   // retire a finished ray
+        const bool finished = my_ray != kNone && st.cur == kSentinel &&
+                              !stack_service<ANY>(st, stack, spill, 0, spilled);
+        if constexpr (!ANY) {
+            const bool to_park = finished && fixup && ordered_is_tie(st);
+            const unsigned long long waiting = __ballot(parked != kNone);
+            if (waiting && ((int)__popcll(waiting) >= kTieBatch || __ballot(to_park && parked2 != kNone)))
+                walk_parked();
+        }
+        if (finished) {                                         // retire a finished ray
             if constexpr (ANY) {
                 bool occ = st.primid >= 0;
                 if (st.tie) {
@@ -743,18 +809,22 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                 }
                 sink(my_ray, occ);
             } else {
-                int32_t shapeid = st.primid >= 0 ? 0 : -1, primid = st.primid;
-                float b0 = st.b0, b1 = st.b1, b2 = st.b2, t = st.tbest;
-                if (ordered_is_tie(st)) {
-                    ++n_ties;
-                }
-                if (fixup && ordered_is_tie(st)) {
-                    unsigned long long xb = 0, xt = 0;
-                    const float4 ro = reinterpret_cast<const float4 *>(rays + my_ray)[0];
-                    const float4 rd = reinterpret_cast<const float4 *>(rays + my_ray)[1];
-                    traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt);
-                }
-                sink(my_ray, shapeid, primid, b0, b1, b2, t);
+                const bool tie = ordered_is_tie(st);
+                n_ties += tie ? 1u : 0u;
+                if (tie && fixup) {
+                    // a complete search's nearest hit bounds the answer; one cut short by a
+                    // non-finite value or a full stack does not
+                    const float lim = (!st.tie && st.primid >= 0) ? st.tbest + st.tbest * PT_TIE_WINDOW
+                                                                  : INFINITY;
+                    if (parked == kNone) {
+                        parked = my_ray;
+                        parked_limit = lim;
+                    } else {
+                        parked2 = my_ray;
+                        parked2_limit = lim;
+                    }
+                } else
+                    sink(my_ray, st.primid >= 0 ? 0 : -1, st.primid, st.b0, st.b1, st.b2, st.tbest);
             }
             my_ray = kNone;
         }
@@ -782,6 +852,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
         }
         ordered_advance<COUNT, ANY>(s, st, stack, pos < stream_len ? 64 - refill : 0, leaf_lanes, nb, nt);
     }
+    if constexpr (!ANY) walk_parked();
     if (!ANY && n_ties) atomicAdd(tie_count, n_ties);
     if (COUNT) {
         nb = wave_sum(nb);

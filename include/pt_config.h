@@ -26,6 +26,10 @@
 #ifndef PT_LDS_STACK_ENTRIES
 #define PT_LDS_STACK_ENTRIES 30
 #endif
+/* Lanes of a wave with a ray waiting for the fixed-order walk that start the walk for all. */
+#ifndef PT_TIE_BATCH
+#define PT_TIE_BATCH 16
+#endif
 /* Threads per workgroup of the traversal kernels (4 wave64). */
 #define PT_TRACE_BLOCK 256
 

@@ -206,6 +206,22 @@ def test_deep_tree_overflows_the_lds_stack_safely(mipt, oracle, gpu_ctx):
     _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays)
 
 
+def test_many_exact_ties_from_duplicated_triangles(mipt, oracle, scenes, gpu_ctx):
+    """Coincident triangles: every hit on one is an exact tie, which the reference's visiting
+    order decides.  With a third of the mesh duplicated (some of it three times) most waves
+    hold several such rays at once; they are re-walked in batches, with the ordered traversal's
+    distance as the starting bound, and must still come out as the fixed-order walk leaves them."""
+    vtx, idx, _, _ = scenes.random_soup(6000, seed=17)
+    idx = np.concatenate([idx, idx[:2000], idx[:700]])
+    nodes = _build(mipt, vtx, idx)
+    rays = random_rays(120000, 23, dtype=mipt.ray_dtype)
+    rays["o"][::7, 3] = 3.0                                   # some with a finite reach
+    got, st = _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays,
+                               expect_ties=lambda t: t > 5000)
+    dup = got["primid"] >= 6000
+    assert dup.sum() > 1000 or (got["primid"] < 2000).sum() > 1000
+
+
 def _comb_tree(oracle, vtx, idx):
     """A hand-made skip-link tree of depth n: inner node i holds triangle i and inner node i+1
     (pre-order: inner_0, leaf_0, inner_1, leaf_1, ..., leaf_{n-2}, leaf_{n-1}; float links)."""

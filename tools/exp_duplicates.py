@@ -1,0 +1,31 @@
+"""Closest-hit rate when part of the mesh is duplicated exactly (coincident triangles: every hit
+on one is an exact tie that the lane re-resolves in the reference's fixed order)."""
+import os, sys, json, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "gpu-pathtracer_amd"))
+import numpy as np
+import torch
+import mipt
+from mipt import scenes
+
+ctx = mipt.Context(0)
+vtx, idx, _, _ = scenes.atrium(262144, seed=42)
+n = 1 << 22
+rays = scenes.surface_rays(vtx, idx, n, seed=7).astype(mipt.ray_dtype)
+d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
+d_h = torch.empty_like(d_r)
+rng = np.random.default_rng(1)
+for frac in (0.0, 0.01, 0.1, 0.5):
+    k = int(frac * idx.shape[0])
+    idx2 = np.concatenate([idx, idx[rng.choice(idx.shape[0], k, replace=False)]]) if k else idx
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx2), mipt.bvh_options(**{"bvh.builder": "sah"}))
+    sc = mipt.Scene(ctx, nodes, vtx, idx2)
+    st = sc.trace_closest_device_counted(d_r.data_ptr(), n, d_h.data_ptr())
+    sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr()); ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr())
+    ctx.synchronize()
+    print(json.dumps({"duplicated_fraction": frac, "mrays_s": round(3 * n / (time.perf_counter() - t0) / 1e6, 1),
+                      "re_resolved_rays": int(st.tie_rays), "boxes_per_ray": round(st.box_tests / n, 1)}), flush=True)
+    sc.close()
