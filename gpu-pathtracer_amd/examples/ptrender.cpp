@@ -35,12 +35,13 @@ static void cross(const double a[3], const double b[3], double out[3]) {
 int main(int argc, char **argv) {
     if (argc < 3) {
         std::fprintf(stderr, "usage: ptrender scene.obj out.ppm|.png|.pfm [--size W H] [--spp N] [--depth D] "
-                             "[--nee] [--gpu-build] [--instanced] [--eye x y z] [--target x y z] [--fov deg] "
+                             "[--nee] [--gpu-build] [--optimize PASSES] [--instanced] [--eye x y z] [--target x y z] [--fov deg] "
                              "[--seed S] [--film out.raw]\n");
         return 2;
     }
     uint32_t W = 512, H = 512, spp = 16, depth = 4, seed = 1;
     bool nee = false, gpu_build = false, instanced = false;
+    int optimize = 0;         // insertion-based optimisation passes over the tree (host or GPU build)
     double eye[3] = {278, 273, -800}, target[3] = {278, 273, 0}, fov = 39.3;
     const char *film_path = nullptr;
     for (int i = 3; i < argc; ++i) {
@@ -56,6 +57,7 @@ int main(int argc, char **argv) {
         else if (a == "--film") { need(1); film_path = argv[++i]; }
         else if (a == "--nee") nee = true;
         else if (a == "--gpu-build") gpu_build = true;
+        else if (a == "--optimize") { need(1); optimize = std::atoi(argv[++i]); }
         else if (a == "--instanced") instanced = true;
         else { std::fprintf(stderr, "ptrender: unknown option %s\n", a.c_str()); return 2; }
     }
@@ -68,6 +70,8 @@ int main(int argc, char **argv) {
     const bool gltf = ends_with(".glb") || ends_with(".gltf");
     pt_context *ctx = nullptr;
     CHECK(pt_context_create(0, &ctx));
+    const std::string passes = std::to_string(optimize);
+    CHECK(pt_context_set_option(ctx, "build.optimize_passes", passes.c_str()));   // trees built on the GPU
     pt_scene *scene = nullptr;
     pt_mesh *mesh = nullptr;
     if (instanced) {
@@ -109,6 +113,7 @@ int main(int argc, char **argv) {
             pt_bvh_options_default(&opt);
             CHECK(pt_bvh_options_set(&opt, "bvh.builder", "sah"));       // src/main_granite.cpp:176
             CHECK(pt_bvh_options_set(&opt, "mipt.link_encoding", "int"));
+            CHECK(pt_bvh_options_set(&opt, "mipt.optimize_passes", passes.c_str()));
             pt_bvh *bvh = nullptr;
             CHECK(pt_bvh_build(leaves.data(), n_tri, &opt, &bvh));
             CHECK(pt_scene_create(ctx, pt_bvh_nodes(bvh), pt_bvh_node_count(bvh), pt_bvh_link_encoding(bvh),

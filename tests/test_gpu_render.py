@@ -297,3 +297,9 @@ def test_cpp_host_program_matches_the_binding(mipt, oracle, scenes, gpu_ctx, tmp
     out = subprocess.run([exe, obj, ppm, "--size", str(W), str(H), "--spp", "2", "--gpu-build"],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
+    first = open(ppm, "rb").read()
+    # optimisation passes change the tree, not the picture (no two Cornell surfaces coincide)
+    out = subprocess.run([exe, obj, ppm, "--size", str(W), str(H), "--spp", "2", "--gpu-build",
+                          "--optimize", "3"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert open(ppm, "rb").read() == first
