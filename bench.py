@@ -217,7 +217,7 @@ def main():
             out["roofline"]["algorithmic_gb_per_launch"] = bytes_per_ray * rays / max(launches, 1) / 1e9
             if "counters" in tr:
                 out["roofline"]["counters"] = tr["counters"]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the host-core baseline belongs to the 1-GPU line
             out["cpu_baseline"] = cpu_baseline(args, nodes, vtx, idx, mats, mids, sky)
             out["traversal_counts_same_rays"] = traversal_counts(scene, nodes, vtx, idx)
         print(json.dumps(out), flush=True)
