@@ -319,6 +319,9 @@ int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
     } else if (k == "build.optimize_passes") {
         if (v < 0 || v > 32) return fail(PT_ERR_INVALID, "build.optimize_passes must be in [0,32]");
         ctx->build_optimize_passes = (int)v;
+    } else if (k == "build.max_levels") {
+        if (v < 8 || v > 256) return fail(PT_ERR_INVALID, "build.max_levels must be in [8,256]");
+        ctx->build_max_levels = (int)v;
     } else if (k == "trace.sort_rays") {
         if (v < -1 || v > 1) return fail(PT_ERR_INVALID, "trace.sort_rays must be -1, 0 or 1");
         ctx->trace_sort_rays = (int)v;
@@ -560,7 +563,7 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
     const DeviceBuildResult br = build_scene_on_device(
         ctx->stream, (const float *)d_vtx, (const int32_t *)d_idx, n_tri, link_encoding, scratch,
         (const int32_t *)d_mid, (float4 *)d_nodes, (float4 *)d_wn, (float4 *)d_wt, (float4 *)d_st,
-        ctx->build_ploc_radius, ctx->build_optimize_passes);
+        ctx->build_ploc_radius, ctx->build_optimize_passes, ctx->build_max_levels);
     (void)hipStreamSynchronize(ctx->stream);
     scratch.release();
     if (br.no_memory || br.hip_error != hipSuccess || br.bad_input) {

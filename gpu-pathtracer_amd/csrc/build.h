@@ -13,6 +13,7 @@ struct DeviceBuildResult {
     const char *what = "";
     bool no_memory = false;              // the scratch allocation failed
     bool bad_input = false;              // a triangle's box is not finite
+    bool too_deep = false;               // the tree outgrew the level lists (handled inside)
     uint32_t max_depth = 0;              // levels of the tree, leaves included
 };
 
@@ -23,11 +24,13 @@ struct DeviceBuildResult {
 // ploc_radius 0: binary
 // radix tree over the Morton codes; > 0: locally-ordered clustering with that search radius.
 // optimize_passes > 0: that many rounds of parallel insertion-based optimisation of the tree.
+// max_levels: an optimised tree deeper than this (at most 256) is given up for the radix tree,
+// whose depth the key length bounds.
 // Blocks until done.
 DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
                                         uint32_t n, uint32_t link_encoding, DeviceBuffer &scratch,
                                         const int32_t *d_mat_ids, float4 *d_nodes,
                                         float4 *d_wnodes, float4 *d_wtris, float4 *d_stris,
-                                        int ploc_radius, int optimize_passes);
+                                        int ploc_radius, int optimize_passes, int max_levels = 256);
 
 } // namespace mipt

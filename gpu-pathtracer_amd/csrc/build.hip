@@ -759,13 +759,11 @@ inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kB - 1) / 
         }                                                 \
     } while (0)
 
-} // namespace
-
-DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
-                                        uint32_t n, uint32_t enc, DeviceBuffer &scratch,
-                                        const int32_t *d_mat_ids, float4 *d_nodes,
-                                        float4 *d_wnodes, float4 *d_wtris, float4 *d_stris,
-                                        int ploc_radius, int optimize_passes) {
+DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
+                             uint32_t n, uint32_t enc, DeviceBuffer &scratch,
+                             const int32_t *d_mat_ids, float4 *d_nodes,
+                             float4 *d_wnodes, float4 *d_wtris, float4 *d_stris,
+                             int ploc_radius, int optimize_passes, int max_levels) {
     DeviceBuildResult res;
     const uint32_t n_inner = n - 1;
     // scratch carve-up
@@ -873,6 +871,7 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
                 begin[d + 1] = begin[d] + h[d];
                 if (h[d]) deepest = d;
             }
+            if (deepest >= max_levels) return hipErrorInvalidValue;
             for (int d = deepest; d >= 0; --d) {
                 const uint32_t cnt = begin[d + 1] - begin[d];
                 if (cnt)
@@ -900,7 +899,8 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
             const hipError_t e = levels_and_refit();
             if (e == hipErrorInvalidValue) {
                 res.hip_error = e;
-                res.what = "optimised tree deeper than 255 levels";
+                res.what = "tree deeper than the level lists";
+                res.too_deep = true;
                 return res;
             }
             BUILD_CHECK(e);
@@ -1046,6 +1046,27 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
     BUILD_CHECK(hipGetLastError());
     BUILD_CHECK(hipStreamSynchronize(st));
     res.max_depth = (uint32_t)max_depth + 2;      // inner levels + the leaf level
+    return res;
+}
+
+} // namespace
+
+DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
+                                        uint32_t n, uint32_t enc, DeviceBuffer &scratch,
+                                        const int32_t *d_mat_ids, float4 *d_nodes,
+                                        float4 *d_wnodes, float4 *d_wtris, float4 *d_stris,
+                                        int ploc_radius, int optimize_passes, int max_levels) {
+    max_levels = std::min(std::max(max_levels, 2), kUMaxDepth);
+    DeviceBuildResult res = build_once(st, d_vtx, d_idx, n, enc, scratch, d_mat_ids, d_nodes, d_wnodes,
+                                       d_wtris, d_stris, ploc_radius, optimize_passes, max_levels);
+    // The optimisation passes can, on contrived input, make a tree deeper than their level
+    // lists reach; the radix tree cannot (its depth is bounded by the key length), so it
+    // is the answer then.  The inputs are untouched and every output is written again.
+    if (res.too_deep && (ploc_radius > 0 || optimize_passes > 0)) {
+        (void)hipGetLastError();
+        res = build_once(st, d_vtx, d_idx, n, enc, scratch, d_mat_ids, d_nodes, d_wnodes, d_wtris,
+                         d_stris, 0, 0, max_levels);
+    }
     return res;
 }
 

@@ -39,6 +39,7 @@ struct pt_context {
     int trace_sort_rays = -1;       // option "trace.sort_rays": 0 off, 1 on, -1 by scene size
     int build_ploc_radius = 0;      // option "build.ploc_radius": 0 = radix tree, else clustering
     int build_optimize_passes = 0;  // option "build.optimize_passes": insertion-based optimisation rounds
+    int build_max_levels = 256;     // option "build.max_levels"
     mipt::DeviceTraceCounters *counters = nullptr;
     mipt::DeviceBuffer io_rays;     // staging for the host-pointer entry points
     mipt::DeviceBuffer io_hits;

@@ -204,8 +204,9 @@ int pt_context_set_kernel_timing(pt_context *ctx, int on);
  * node looks for the place where it would add the least surface area, and the moves that do
  * not touch each other's nodes are made.  About 1.5 ms per pass and million triangles; 16
  * passes bring the radix tree of a million-triangle scene from 75 % to 96 % of the host SAH
- * tree's closest-hit rate.  Deterministic; the build fails with PT_ERR_HIP if the optimised
- * tree is deeper than 255 levels. */
+ * tree's closest-hit rate.  Deterministic.  "build.max_levels" 8..256 (default 256): an
+ * optimised tree with more levels than this is given up for the plain radix tree, whose
+ * depth the key length bounds (256 is what the level lists of the passes hold). */
 int pt_context_set_option(pt_context *ctx, const char *key, const char *value);
 int pt_context_destroy(pt_context *ctx);
 

@@ -151,3 +151,60 @@ def test_optimisation_passes_improve_the_tree(mipt, scenes, gpu_ctx, algorithm):
         # the nearest distance does not depend on the tree; which of two triangles at one distance
         # is reported may
         np.testing.assert_array_equal(h["uvwt"][:, 3], hits[0]["uvwt"][:, 3])
+
+
+def _levels(nodes):
+    raw = nodes.view(np.float32).reshape(-1, 8)
+    payload, link = raw[:, 3].astype(np.int64), raw[:, 7].astype(np.int64)
+    d = np.zeros(len(raw), dtype=np.int64)
+    for i in range(len(raw)):
+        if payload[i] < 0:
+            d[i + 1] = d[i] + 1
+            d[link[i + 1]] = d[i] + 1
+    return int(d.max()) + 1
+
+
+def test_too_deep_a_tree_falls_back_to_the_radix_tree(mipt, oracle, gpu_ctx, algorithm):
+    """Optimised trees have no depth bound of their own; the level lists the passes work with do
+    (256).  Past the limit the build answers with the radix tree instead of failing.  The limit
+    is lowered here (option build.max_levels) so that ordinary input reaches it."""
+    if algorithm != (0, 0):
+        pytest.skip("sets the options itself")
+    n = 400
+    x = 1.08 ** np.arange(n, dtype=np.float64)
+    tri = np.array([[0, -1, -1], [0, 1, -1], [0, 0, 1]], dtype=np.float64) * 0.02
+    vtx = (tri[None] * x[:, None, None] + np.stack([x, 0 * x, 0 * x], 1)[:, None]).reshape(-1, 3).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+    rays = np.zeros(2 * n, dtype=mipt.ray_dtype)
+    rays["o"][:n] = [(-1, 0, 0, 1e30)] * n
+    rays["d"][:n, 0] = 1
+    rays["o"][n:, 0] = (x * 1.01).astype(np.float32)
+    rays["o"][n:, 3] = 1e30
+    rays["d"][n:, 0] = -1
+    levels = {}
+    try:
+        for limit in (256, 36):
+            gpu_ctx.set_option("build.max_levels", limit)
+            for radius, passes in ((0, 0), (8, 0), (8, 2), (0, 4)):
+                gpu_ctx.set_option("build.ploc_radius", radius)
+                gpu_ctx.set_option("build.optimize_passes", passes)
+                sc = mipt.Scene(gpu_ctx, None, vtx, idx)
+                try:
+                    nodes = sc.read_nodes()
+                    _check_tree(mipt, oracle, nodes, vtx, idx, mipt.PT_LINKS_FLOAT_VALUE)
+                    levels[limit, radius, passes] = _levels(nodes)
+                    got = sc.trace_closest(rays)
+                    assert len(same_hits(got, oracle.closest(nodes, vtx, idx, rays), True)) == 0
+                    assert (got["primid"] >= 0).mean() > 0.9
+                finally:
+                    sc.close()
+    finally:
+        gpu_ctx.set_option("build.ploc_radius", 0)
+        gpu_ctx.set_option("build.optimize_passes", 0)
+        gpu_ctx.set_option("build.max_levels", 256)
+    radix = levels[256, 0, 0]
+    assert radix <= 36 and levels[36, 0, 0] == radix
+    for radius, passes in ((8, 2), (0, 4)):
+        assert levels[256, radius, passes] > 36, levels            # deeper than the lowered limit ...
+        assert levels[36, radius, passes] == radix, levels         # ... so the radix tree it is
+    assert levels[36, 8, 0] == levels[256, 8, 0]                   # plain clustering needs no level lists
