@@ -65,7 +65,7 @@ __device__ __forceinline__ void traverse_skiplink(const DeviceScene &s, const fl
     shapeid = -1; primid = -1;                              // :424-425
     int32_t idx = 0;
     // limit: a distance beyond which the caller knows the answer does not lie (the nearest hit
-    // of the ordered traversal, widened by the tie window).  The walk starts culling there
+    // of the ordered traversal, widened by the tie window and a margin for rounding).  The walk starts culling there
     // instead of at r.o.w: hits beyond it would be replaced before the walk ends, so skipping
     // them and the boxes only they need leaves the result as it is.
     if (!MT && limit < tbest) {
@@ -814,8 +814,19 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                 if (tie && fixup) {
                     // a complete search's nearest hit bounds the answer; one cut short by a
                     // non-finite value or a full stack does not
-                    const float lim = (!st.tie && st.primid >= 0) ? st.tbest + st.tbest * PT_TIE_WINDOW
-                                                                  : INFINITY;
+                    float lim = INFINITY;
+                    if (!st.tie && st.primid >= 0) {
+                        // The walk must enter every box on the way to that hit.  A box's computed
+                        // entry distance can lie past the computed hit distance by rounding (a flat
+                        // triangle's box has no depth): by a few units in the last place of the
+                        // coordinates involved, times 1/d.  64 of them, taken at the scene's
+                        // largest coordinates, are added; a ray along an axis gets no bound.
+                        const float4 lo = s.nodes[0], hi = s.nodes[1];
+                        const float ex = (fabsf(st.r.ox) + fmaxf(fabsf(lo.x), fabsf(hi.x))) * fabsf(st.r.ix);
+                        const float ey = (fabsf(st.r.oy) + fmaxf(fabsf(lo.y), fabsf(hi.y))) * fabsf(st.r.iy);
+                        const float ez = (fabsf(st.r.oz) + fmaxf(fabsf(lo.z), fabsf(hi.z))) * fabsf(st.r.iz);
+                        lim = (st.tbest + st.tbest * PT_TIE_WINDOW) + 3.814697265625e-06f * fmaxf(ex, fmaxf(ey, ez));
+                    }
                     if (parked == kNone) {
                         parked = my_ray;
                         parked_limit = lim;

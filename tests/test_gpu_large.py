@@ -128,3 +128,37 @@ def test_cornell_1080p_64spp_depth4_full_size(mipt, oracle, scenes, gpu_ctx):
     finally:
         film.close()
         sc.close()
+
+
+def test_millions_of_rays_with_ties_and_deep_trees_match_the_oracle(mipt, oracle, scenes, gpu_ctx):
+    """Bit-exact hits at a ray count where rare rounding cases show up: 2 M incoherent rays on
+    the benchmark scene with a tenth of its triangles duplicated (150 000 exact ties, re-walked
+    in batches from a bounded start; flat wall triangles have boxes without depth, whose entry
+    distance can round past the hit distance), and on a GPU-built, GPU-optimised million-triangle
+    tree read back from the device."""
+    n = 1 << 21
+    vtx, idx, _, _ = scenes.atrium(262144, seed=42)
+    rng = np.random.default_rng(3)
+    idx2 = np.concatenate([idx, idx[rng.choice(idx.shape[0], idx.shape[0] // 10, replace=False)]])
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx2), mipt.bvh_options(**{"bvh.builder": "sah"}))
+    rays = scenes.surface_rays(vtx, idx, n, seed=5).astype(mipt.ray_dtype)
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx2)
+    try:
+        got, st = sc.trace_closest(rays, stats=True)
+        assert st.tie_rays > 100_000
+        assert len(same_hits(got, oracle.closest(nodes, vtx, idx2, rays, nthreads=16))) == 0
+    finally:
+        sc.close()
+    vtx, idx, _, _ = scenes.clutter(1_000_000, seed=11)
+    rays = scenes.surface_rays(vtx, idx, n, seed=9).astype(mipt.ray_dtype)
+    gpu_ctx.set_option("build.optimize_passes", 16)
+    try:
+        sc = mipt.Scene(gpu_ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
+    finally:
+        gpu_ctx.set_option("build.optimize_passes", 0)
+    try:
+        nodes = sc.read_nodes()
+        got = sc.trace_closest(rays)
+        assert len(same_hits(got, oracle.closest(nodes, vtx, idx, rays, nthreads=16, int_bits=True))) == 0
+    finally:
+        sc.close()

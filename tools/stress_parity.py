@@ -1,0 +1,56 @@
+"""Bit-exact comparison with the CPU restatement at sizes beyond the test suite's: millions of
+rays on (a) a 262 K-triangle scene with a tenth of its triangles duplicated (every hit there is
+a tie re-walked in batches) and (b) a GPU-built, GPU-optimised tree of a million triangles
+(deep enough for stacks to spill).  Prints one JSON line per case."""
+import json, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(REPO, "gpu-pathtracer_amd"), REPO):
+    sys.path.insert(0, p)
+import numpy as np
+import mipt
+from mipt import scenes
+from oracle import oracle
+
+oracle.build()
+ctx = mipt.Context(0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 21
+
+
+def compare(label, sc, nodes, vtx, idx, rays, int_bits):
+    got, st = sc.trace_closest(rays, stats=True)
+    t0 = time.time()
+    want = oracle.closest(nodes, vtx, idx, rays, nthreads=16, int_bits=int_bits)
+    same = (got["primid"] == want["primid"]) & (got["shapeid"] == want["shapeid"]) & \
+           (got["uvwt"].view(np.uint32) == want["uvwt"].view(np.uint32)).all(axis=1)
+    for i in np.nonzero(~same)[:1][0][:4]:
+        exact = sc.trace_closest(rays[i:i + 1], mipt.PT_TRACE_EXACT_ORDER)
+        print("differs: ray", int(i), "o", rays["o"][i].tolist(), "d", rays["d"][i].tolist(),
+              "\n  ordered kernel", got[i], "\n  restatement   ", want[i], "\n  fixed-order kernel", exact[0],
+              "\n  t bits", hex(int(got["uvwt"][i, 3].view(np.uint32))), hex(int(want["uvwt"][i, 3].view(np.uint32))),
+              flush=True)
+    print(json.dumps({"case": label, "rays": len(rays), "differing": int((~same).sum()),
+                      "re_resolved": int(st.tie_rays), "hit_fraction": round(float((got["primid"] >= 0).mean()), 3),
+                      "oracle_s": round(time.time() - t0, 1)}), flush=True)
+    return int((~same).sum())
+
+
+bad = 0
+vtx, idx, _, _ = scenes.atrium(262144, seed=42)
+rng = np.random.default_rng(3)
+idx2 = np.concatenate([idx, idx[rng.choice(idx.shape[0], idx.shape[0] // 10, replace=False)]])
+nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx2), mipt.bvh_options(**{"bvh.builder": "sah"}))
+rays = scenes.surface_rays(vtx, idx, n, seed=5).astype(mipt.ray_dtype)
+sc = mipt.Scene(ctx, nodes, vtx, idx2)
+bad += compare("atrium, 10 % duplicated triangles, host SAH tree", sc, nodes, vtx, idx2, rays, False)
+sc.close()
+
+vtx, idx, _, _ = scenes.clutter(1_000_000, seed=11)
+rays = scenes.surface_rays(vtx, idx, n, seed=9).astype(mipt.ray_dtype)
+for radius, passes in ((0, 16), (8, 4)):
+    ctx.set_option("build.ploc_radius", radius)
+    ctx.set_option("build.optimize_passes", passes)
+    sc = mipt.Scene(ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
+    nodes = sc.read_nodes()
+    bad += compare(f"clutter 1 M, GPU tree (radius {radius}, {passes} passes)", sc, nodes, vtx, idx, rays, True)
+    sc.close()
+sys.exit(1 if bad else 0)
