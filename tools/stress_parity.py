@@ -1,7 +1,7 @@
 """Bit-exact comparison with the CPU restatement at sizes beyond the test suite's: millions of
 rays on (a) a 262 K-triangle scene with a tenth of its triangles duplicated (every hit there is
 a tie re-walked in batches) and (b) a GPU-built, GPU-optimised tree of a million triangles
-(deep enough for stacks to spill).  Prints one JSON line per case."""
+(deep enough for stacks to spill), and (c) whole path-traced frames of the benchmark scene.  Prints one JSON line per case."""
 import json, os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(REPO, "gpu-pathtracer_amd"), REPO):
@@ -53,4 +53,26 @@ for radius, passes in ((0, 16), (8, 4)):
     nodes = sc.read_nodes()
     bad += compare(f"clutter 1 M, GPU tree (radius {radius}, {passes} passes)", sc, nodes, vtx, idx, rays, True)
     sc.close()
+
+# (c) whole frames: the wavefront path tracer against the CPU restatement of the same step
+vtx, idx, mats, mids = scenes.atrium(262144, seed=42)
+nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+sc = mipt.Scene(ctx, nodes, vtx, idx, mats, mids)
+W, H = (1920, 1080) if n > (1 << 22) else (960, 540)
+cam = scenes.atrium_camera(W / H)
+film = mipt.Film(ctx, W, H)
+for flags, label in ((0, "atrium %dx%d, 4 spp, depth 8" % (W, H)), (mipt.PT_RENDER_NEE, "the same with next-event estimation")):
+    film.clear()
+    p = mipt.render_params(W, H, sample_count=4, max_depth=8, seed=42, rr_start_depth=3,
+                           background=(0.55, 0.65, 0.8), flags=flags)
+    st = mipt.render(ctx, sc, cam, p, film, stats=True)
+    t0 = time.time()
+    want, _ = oracle.render(nodes, vtx, idx, mats, mids, cam, p, nthreads=16)
+    got = film.read()
+    diff = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=-1).sum())
+    print(json.dumps({"case": label, "rays": int(st.rays_primary + st.rays_bounce + st.rays_shadow),
+                      "differing_pixels": diff, "oracle_s": round(time.time() - t0, 1)}), flush=True)
+    bad += diff
+film.close()
+sc.close()
 sys.exit(1 if bad else 0)
