@@ -54,6 +54,62 @@ for radius, passes in ((0, 16), (8, 4)):
     bad += compare(f"clutter 1 M, GPU tree (radius {radius}, {passes} passes)", sc, nodes, vtx, idx, rays, True)
     sc.close()
 
+# (b2) occlusion queries on the tie-heavy scene (finite reach, so that some are blocked)
+vtx, idx, _, _ = scenes.atrium(262144, seed=42)
+nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+rays = scenes.surface_rays(vtx, idx, n, seed=6).astype(mipt.ray_dtype)
+rays["o"][:, 3] = np.random.default_rng(8).uniform(0.05, 6.0, n).astype(np.float32)
+sc = mipt.Scene(ctx, nodes, vtx, idx)
+got = sc.trace_any(rays)
+t0 = time.time()
+want = oracle.any_hit(nodes, vtx, idx, rays, nthreads=16)
+d = int((got != want).sum())
+print(json.dumps({"case": "atrium, occlusion queries", "rays": n, "differing": d,
+                  "occluded_fraction": round(float(got.mean()), 3), "oracle_s": round(time.time() - t0, 1)}), flush=True)
+bad += d
+sc.close()
+
+# (b3) a two-level scene: 400 placements (rotated, scaled, some mirrored, some coincident) of
+# two meshes of 20 000 triangles
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import two_level_util as tl
+rng = np.random.default_rng(12)
+meshes = [tl.blob_mesh(20000, 1), tl.blob_mesh(20000, 2)]
+tr, mesh_of = [], []
+for k in range(400):
+    lin = tl._rot(rng.normal(size=3), rng.uniform(0, 6.28)) @ np.diag(rng.uniform(0.5, 1.5, size=3))
+    if k % 5 == 4:
+        lin = lin @ np.diag([-1.0, 1.0, 1.0])
+    tr.append(tl._affine(lin, rng.uniform(-30, 30, size=3) * (1, 0.3, 1)))
+    mesh_of.append(k % 2)
+tr += [tr[3].copy(), tr[10].copy()]
+mesh_of += [mesh_of[3], mesh_of[10]]
+tr = np.stack(tr)
+opt = mipt.bvh_options(**{"bvh.builder": "sah"})
+built = [(mipt.build_bvh(mipt.mesh_leaf_bounds(v, i), opt), v, i, m) for v, i, m in meshes]
+top = mipt.build_bvh(mipt.instance_bounds(built, tr, mesh_of), opt)
+t = oracle.TwoLevel([b[:3] for b in built], tr, mesh_of, top)
+sc = mipt.Scene.instanced(ctx, built, tr, mesh_of, top, materials=tl.materials(mipt))
+m = min(n, 1 << 22)
+rays = np.zeros(m, dtype=mipt.ray_dtype)
+rays["o"][:, :3] = rng.uniform(-40, 40, size=(m, 3)).astype(np.float32) * (1, 0.4, 1)
+rays["o"][:, 3] = 1e30
+dd = rng.uniform(-30, 30, size=(m, 3)) * (1, 0.3, 1) - rays["o"][:, :3]
+rays["d"][:, :3] = (dd / np.linalg.norm(dd, axis=1, keepdims=True)).astype(np.float32)
+got, st = sc.trace_closest(rays, stats=True)
+t0 = time.time()
+want = t.closest(rays, nthreads=16)
+same = (got["primid"] == want["primid"]) & (got["shapeid"] == want["shapeid"]) & \
+       (got["uvwt"].view(np.uint32) == want["uvwt"].view(np.uint32)).all(axis=1)
+d = int((~same).sum())
+d2 = int((sc.trace_any(rays) != t.any_hit(rays, nthreads=16)).sum())
+print(json.dumps({"case": "two-level, 402 instances of 20 000-triangle meshes", "rays": m, "differing": d,
+                  "differing_occlusion": d2, "re_resolved": int(st.tie_rays),
+                  "hit_fraction": round(float((got["primid"] >= 0).mean()), 3),
+                  "oracle_s": round(time.time() - t0, 1)}), flush=True)
+bad += d + d2
+sc.close()
+
 # (c) whole frames: the wavefront path tracer against the CPU restatement of the same step
 vtx, idx, mats, mids = scenes.atrium(262144, seed=42)
 nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
