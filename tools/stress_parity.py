@@ -53,6 +53,25 @@ for radius, passes in ((0, 16), (8, 4)):
     nodes = sc.read_nodes()
     bad += compare(f"clutter 1 M, GPU tree (radius {radius}, {passes} passes)", sc, nodes, vtx, idx, rays, True)
     sc.close()
+ctx.set_option("build.ploc_radius", 0)
+ctx.set_option("build.optimize_passes", 0)
+
+# (b1) optional: a 9 M-triangle tree (18 M nodes, integer links) built and optimised on the GPU:
+# structure checked on the host, a sample of rays against the restatement walking that tree
+if len(sys.argv) > 2 and sys.argv[2] == "big":
+    vtx, idx, _, _ = scenes.clutter(9_000_000, seed=11)
+    rays = scenes.surface_rays(vtx, idx, 1 << 20, seed=13).astype(mipt.ray_dtype)
+    for radius, passes in ((0, 8), (8, 2)):
+        ctx.set_option("build.ploc_radius", radius)
+        ctx.set_option("build.optimize_passes", passes)
+        sc = mipt.Scene(ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
+        nodes = sc.read_nodes()
+        mipt.validate_bvh(nodes, idx.shape[0], mipt.PT_LINKS_INT_BITS)
+        bad += compare(f"clutter 9 M, GPU tree (radius {radius}, {passes} passes), structure valid", sc, nodes,
+                       vtx, idx, rays, True)
+        sc.close()
+    ctx.set_option("build.ploc_radius", 0)
+    ctx.set_option("build.optimize_passes", 0)
 
 # (b2) occlusion queries on the tie-heavy scene (finite reach, so that some are blocked)
 vtx, idx, _, _ = scenes.atrium(262144, seed=42)
