@@ -18,8 +18,9 @@
 // among candidates whose distances are within a few ulp of each other does (the shader
 // accepts an equal-distance triangle visited later, bvh.glslh:268-273).  The ordered
 // traversal keeps its culling distance a factor 1+PT_TIE_WINDOW above its nearest hit,
-// so it sees every candidate in that window; a ray with two or more (a few per million
-// on ordinary scenes) is traversed again, by the same lane, in the shader's fixed order.
+// so it sees every candidate in that window; a ray with two or more (a few per million on
+// ordinary scenes), or with a hit within the window of its own reach, is traversed again in the
+// shader's fixed order.
 // A ray with one gets that one from either order.
 #pragma once
 
@@ -172,7 +173,9 @@ __device__ __forceinline__ void traverse_ordered(const DeviceScene &s, const flo
     const float tmax = ro.w;
     b0 = 0.f; b1 = 0.f; b2 = 0.f;
     tbest = tmax;                // nearest accepted distance (tmax while there is none)
-    float bound = tmax;          // culling distance: tbest widened by the tie window
+    // culling distance: tbest widened by the tie window, and so is the reach while there is no
+    // hit (see the note on hits near the reach at the triangle step of ordered_advance)
+    float bound = tmax + tmax * PT_TIE_WINDOW;
     float second = INFINITY;     // nearest distance among the other candidates seen
     primid = -1;
     tie = false;
@@ -236,7 +239,8 @@ __device__ __forceinline__ void traverse_ordered(const DeviceScene &s, const flo
                     if (primid >= 0) second = fminf(second, tbest);
                     tbest = ht; b0 = h0; b1 = h1; b2 = h2;
                     primid = __float_as_int(q2.y);
-                    bound = fminf(tbest + tbest * PT_TIE_WINDOW, tmax);
+                    bound = tbest + tbest * PT_TIE_WINDOW;
+                    tie |= bound >= tmax;
                 } else if (__float_as_int(q2.y) != primid) {
                     second = fminf(second, ht);
                 }   // else: another leaf of the same triangle (a tree built with spatial splits)
@@ -283,7 +287,7 @@ __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro,
     st.tmax = ro.w;
     st.b0 = 0.f; st.b1 = 0.f; st.b2 = 0.f;
     st.tbest = st.tmax;
-    st.bound = st.tmax;
+    st.bound = st.tmax + st.tmax * PT_TIE_WINDOW;     // see the triangle step of ordered_advance
     st.second = INFINITY;
     st.primid = -1;
     st.tie = false;
@@ -423,9 +427,14 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
             st.b1 = closer ? h1 : st.b1;
             st.b2 = closer ? h2 : st.b2;
             st.primid = closer ? __float_as_int(q2.y) : st.primid;
-            const float nbound = fminf(ht + ht * PT_TIE_WINDOW, st.tmax);
+            // Hits near the ray's reach: the test compares products, so a distance an ulp beyond
+            // the reach can be accepted -- and the shader then culls at that distance, which lets
+            // in a triangle it had turned down at the reach itself, or would have, had it come
+            // first.  The reach is therefore widened like every culling distance (ordered_begin),
+            // and a ray with a hit within the window of its reach is left to the fixed order.
+            const float nbound = ht + ht * PT_TIE_WINDOW;
             st.bound = closer ? nbound : st.bound;
-            st.tie |= bad;
+            st.tie |= bad | (hit & !bad & (nbound >= st.tmax));
             --st.sp;
             const int32_t popped = stack[st.sp * kTraceBlock];
             st.cur = bad ? kSentinel : popped;
@@ -953,7 +962,7 @@ __device__ __forceinline__ void persistent_traverse_two_level(
                             if (best_prim >= 0) second = fminf(second, best_t);
                             best_shape = cur_inst; best_prim = pid;
                             best_b0 = st.b0; best_b1 = st.b1; best_b2 = st.b2; best_t = ct;
-                            bound = fminf(ct + ct * PT_TIE_WINDOW, ro.w);
+                            bound = ct + ct * PT_TIE_WINDOW;
                         } else if (cur_inst != best_shape || pid != best_prim) {
                             second = fminf(second, ct);
                         }   // else: the same instance reached through another top-level leaf

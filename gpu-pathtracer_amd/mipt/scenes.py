@@ -337,3 +337,41 @@ def surface_rays(vtx, idx, n_rays: int, seed: int = 7, tmax: float = 1e30):
     rays["o"][:, 3] = tmax
     rays["d"][:, :3] = d.astype(np.float32)
     return rays
+
+
+def awkward_rays(vtx, idx, m, seed=0):
+    """Rays made to be awkward for a scene of axis-aligned walls: along the axes through vertices
+    and edge midpoints, from vertex to vertex (in the planes of the walls, through shared edges),
+    starting on a surface, starting very far away; a fifth with a short reach, often exactly the
+    distance to the surface aimed at."""
+    ray_dtype = np.dtype([("o", np.float32, 4), ("d", np.float32, 4)])
+    rng = np.random.default_rng(seed)
+    tri = idx[rng.integers(0, idx.shape[0], m)]
+    corner = vtx[tri[:, 0]]
+    mid = (vtx[tri[:, 0]] + vtx[tri[:, 1]]) * np.float32(0.5)
+    rays = np.zeros(m, dtype=ray_dtype)
+    kind = rng.integers(0, 6, m)
+    axis = rng.integers(0, 3, m)
+    sign = rng.choice(np.float32([-1, 1]), m)
+    e = np.zeros((m, 3), dtype=np.float32)
+    e[np.arange(m), axis] = sign
+    target = np.where((kind % 2 == 0)[:, None], corner, mid)
+    dist = rng.choice(np.float32([0.5, 3.0, 40.0, 1e6]), m)
+    o = target - e * dist[:, None]                          # kinds 0,1: along an axis through a vertex / an edge midpoint
+    d = e.copy()
+    other = vtx[idx[rng.integers(0, idx.shape[0], m), 1]]
+    v2v = (kind == 2) | (kind == 3)                         # kinds 2,3: from one vertex (or just off it) to another
+    o[v2v] = corner[v2v] + np.where((kind[v2v] == 3)[:, None], np.float32(1e-3) * e[v2v], 0)
+    dd = other[v2v] - o[v2v]
+    dd[np.abs(dd).sum(axis=1) == 0] = (1, 0, 0)
+    d[v2v] = dd / np.linalg.norm(dd, axis=1, keepdims=True)
+    onsurf = kind >= 4                                      # kinds 4,5: from a point of a surface, random direction
+    w = rng.dirichlet((1, 1, 1), m).astype(np.float32)
+    p_on = (vtx[tri[:, 0]] * w[:, :1] + vtx[tri[:, 1]] * w[:, 1:2] + vtx[tri[:, 2]] * w[:, 2:])
+    o[onsurf] = p_on[onsurf]
+    rd = rng.normal(size=(m, 3)).astype(np.float32)
+    d[onsurf] = (rd / np.linalg.norm(rd, axis=1, keepdims=True))[onsurf]
+    rays["o"][:, :3] = o
+    rays["d"][:, :3] = d
+    rays["o"][:, 3] = np.where(rng.random(m) < 0.2, rng.choice(np.float32([1e-6, 1e-3, 0.5, 3.0]), m), np.float32(1e30))
+    return rays

@@ -162,3 +162,28 @@ def test_millions_of_rays_with_ties_and_deep_trees_match_the_oracle(mipt, oracle
         assert len(same_hits(got, oracle.closest(nodes, vtx, idx, rays, nthreads=16, int_bits=True))) == 0
     finally:
         sc.close()
+
+
+def test_awkward_rays_match_the_oracle(mipt, oracle, scenes, gpu_ctx):
+    """A million rays built to sit on the scene's special cases: along the axes through vertices
+    and edge midpoints of the axis-aligned walls, from vertex to vertex inside the planes of the
+    walls, from points on surfaces, from a million units away, and a fifth of them with a reach
+    that ends exactly on the surface aimed at.  The last kind is where the fixed order matters in
+    a way no pair of near-equal hits shows: a distance that rounds to an ulp beyond the reach can
+    be accepted, after which the shader culls at that distance and lets in a triangle it would
+    have turned down at the reach itself."""
+    vtx, idx, _, _ = scenes.atrium(262144, seed=42)
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+    rays = scenes.awkward_rays(vtx, idx, 1 << 20, seed=21).astype(mipt.ray_dtype)
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx)
+    try:
+        want = oracle.closest(nodes, vtx, idx, rays, nthreads=16)
+        for persistent in (1, 0):
+            gpu_ctx.set_option("extend.persistent", persistent)
+            got, st = sc.trace_closest(rays, stats=True)
+            assert len(same_hits(got, want)) == 0
+            assert st.tie_rays > 100_000 and 0.6 < (got["primid"] >= 0).mean() < 0.95
+        np.testing.assert_array_equal(sc.trace_any(rays), oracle.any_hit(nodes, vtx, idx, rays, nthreads=16))
+    finally:
+        gpu_ctx.set_option("extend.persistent", 1)
+        sc.close()

@@ -73,6 +73,22 @@ if len(sys.argv) > 2 and sys.argv[2] == "big":
     ctx.set_option("build.ploc_radius", 0)
     ctx.set_option("build.optimize_passes", 0)
 
+# (a2) rays made to be awkward on the benchmark scene (axis-aligned walls): along the axes through
+# vertices and edge midpoints, from vertex to vertex (in the planes of the walls, through shared
+# edges), starting on a surface, starting very far away, with a reach of almost nothing
+vtx, idx, _, _ = scenes.atrium(262144, seed=42)
+nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+m = min(n, 1 << 21)
+rays = scenes.awkward_rays(vtx, idx, m, seed=21).astype(mipt.ray_dtype)
+sc = mipt.Scene(ctx, nodes, vtx, idx)
+bad += compare("atrium, awkward rays (axes through vertices, vertex to vertex, on surfaces, far away)", sc, nodes,
+               vtx, idx, rays, False)
+got = sc.trace_any(rays)
+d_any = int((got != oracle.any_hit(nodes, vtx, idx, rays, nthreads=16)).sum())
+print(json.dumps({"case": "the same rays, occlusion", "rays": m, "differing": d_any}), flush=True)
+bad += d_any
+sc.close()
+
 # (b2) occlusion queries on the tie-heavy scene (finite reach, so that some are blocked)
 vtx, idx, _, _ = scenes.atrium(262144, seed=42)
 nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
