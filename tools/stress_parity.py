@@ -143,6 +143,45 @@ print(json.dumps({"case": "two-level, 402 instances of 20 000-triangle meshes", 
                   "hit_fraction": round(float((got["primid"] >= 0).mean()), 3),
                   "oracle_s": round(time.time() - t0, 1)}), flush=True)
 bad += d + d2
+# the same scene with awkward rays: aimed at the (approximate) world positions of vertices
+wv, wi, off = [], [], 0
+for k in range(0, tr.shape[0], 7):
+    v, i, _ = meshes[mesh_of[k]]
+    wv.append((v.astype(np.float64) @ tr[k][:, :3].astype(np.float64).T + tr[k][:, 3]).astype(np.float32))
+    wi.append(i + off)
+    off += v.shape[0]
+rays = scenes.awkward_rays(np.concatenate(wv), np.concatenate(wi), min(n, 1 << 20), seed=33).astype(mipt.ray_dtype)
+got, st = sc.trace_closest(rays, stats=True)
+want = t.closest(rays, nthreads=16)
+same = (got["primid"] == want["primid"]) & (got["shapeid"] == want["shapeid"]) & \
+       ((got["uvwt"].view(np.uint32) == want["uvwt"].view(np.uint32)) | (np.isnan(got["uvwt"]) & np.isnan(want["uvwt"]))).all(axis=1)
+d = int((~same).sum())
+for i in np.nonzero(~same)[0][:3]:
+    print("differs: ray", int(i), rays[i], "\n  gpu", got[i], "\n  cpu", want[i], flush=True)
+d2 = int((sc.trace_any(rays) != t.any_hit(rays, nthreads=16)).sum())
+print(json.dumps({"case": "two-level, awkward rays", "rays": len(rays), "differing": d, "differing_occlusion": d2,
+                  "re_resolved": int(st.tie_rays), "hit_fraction": round(float((got["primid"] >= 0).mean()), 3)}), flush=True)
+bad += d + d2
+sc.close()
+
+# (b4) the Cornell box (32 triangles, every surface axis-aligned): awkward rays, and a whole frame
+vtx, idx, mats, mids = scenes.cornell_box()
+nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+sc = mipt.Scene(ctx, nodes, vtx, idx, mats, mids)
+rays = scenes.awkward_rays(vtx, idx, min(n, 1 << 20), seed=44).astype(mipt.ray_dtype)
+bad += compare("Cornell box, awkward rays", sc, nodes, vtx, idx, rays, False)
+d_any = int((sc.trace_any(rays) != oracle.any_hit(nodes, vtx, idx, rays, nthreads=16)).sum())
+Wc, Hc = 960, 540
+camc = mipt.look_at_camera((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), fovy_deg=39.3, aspect=Wc / Hc)
+filmc = mipt.Film(ctx, Wc, Hc)
+pc = mipt.render_params(Wc, Hc, sample_count=8, max_depth=6, seed=3, flags=mipt.PT_RENDER_NEE)
+mipt.render(ctx, sc, camc, pc, filmc)
+wantc, _ = oracle.render(nodes, vtx, idx, mats, mids, camc, pc, nthreads=16)
+d_film = int((filmc.read().view(np.uint32) != wantc.view(np.uint32)).any(axis=-1).sum())
+print(json.dumps({"case": "Cornell box: occlusion of the same rays; 960x540 frame, 8 spp, depth 6, next-event estimation",
+                  "differing": d_any, "differing_pixels": d_film}), flush=True)
+bad += d_any + d_film
+filmc.close()
 sc.close()
 
 # (c) whole frames: the wavefront path tracer against the CPU restatement of the same step
