@@ -122,7 +122,7 @@ __device__ __forceinline__ void traverse_skiplink(const DeviceScene &s, const fl
                     float m1, m2, temp;
                     moller_trumbore(r.ox, r.oy, r.oz, rd.x, rd.y, rd.z, v0x, v0y, v0z, v1x, v1y,
                                     v1z, v2x, v2y, v2z, m1, m2, temp);
-                    temp = fmaxf(0.0f, temp);               // :191
+                    temp = (0.0f < temp) ? temp : 0.0f;     // :191, max() as GLSL defines it (+0 for -0)
                     if (!(m1 < -PT_MT_EPS || m1 > 1.f + PT_MT_EPS || m2 < -PT_MT_EPS ||
                           m1 + m2 > 1.f + PT_MT_EPS || temp < -PT_MT_EPS ||
                           temp > tbest + PT_MT_EPS)) {       // :193

@@ -76,7 +76,10 @@ int o_intersect_triangle_mt(const o_ray *r, const float v1[3], const float v2[3]
     const float b1 = dot3(d, s1) * invd;
     cross3(d, e1, s2);
     const float b2 = dot3(r->d, s2) * invd;
-    const float temp = fmaxf(0.0f, dot3(e2, s2) * invd);
+    /* max(0.0, x) as GLSL defines it (y if x < y, else x): +0 for x = -0, 0 for NaN.  fmaxf
+     * leaves the sign of a zero result to the implementation. */
+    const float traw = dot3(e2, s2) * invd;
+    const float temp = (0.0f < traw) ? traw : 0.0f;
     if (b1 < -O_EPS || b1 > 1.0f + O_EPS || b2 < -O_EPS || b1 + b2 > 1.0f + O_EPS ||
         temp < -O_EPS || temp > isect->uvwt[3] + O_EPS)
         return 0;

@@ -184,6 +184,11 @@ def test_awkward_rays_match_the_oracle(mipt, oracle, scenes, gpu_ctx):
             assert len(same_hits(got, want)) == 0
             assert st.tie_rays > 100_000 and 0.6 < (got["primid"] >= 0).mean() < 0.95
         np.testing.assert_array_equal(sc.trace_any(rays), oracle.any_hit(nodes, vtx, idx, rays, nthreads=16))
+        # the shader's Moller-Trumbore closest hit clamps the distance with max(0, t): +0 for t = -0
+        mt = sc.trace_closest(rays, mipt.PT_TRACE_MOLLER_TRUMBORE)
+        want_mt = oracle.closest(nodes, vtx, idx, rays, nthreads=16, moller_trumbore=True)
+        assert len(same_hits(mt, want_mt, True)) == 0
+        assert (mt["uvwt"][:, 3].view(np.uint32) == 0x80000000).sum() == 0
     finally:
         gpu_ctx.set_option("extend.persistent", 1)
         sc.close()

@@ -87,7 +87,37 @@ got = sc.trace_any(rays)
 d_any = int((got != oracle.any_hit(nodes, vtx, idx, rays, nthreads=16)).sum())
 print(json.dumps({"case": "the same rays, occlusion", "rays": m, "differing": d_any}), flush=True)
 bad += d_any
+# the Moller-Trumbore closest-hit variant of the shader (bvh.glslh:181-202), fixed order only
+got = sc.trace_closest(rays, mipt.PT_TRACE_MOLLER_TRUMBORE)
+want = oracle.closest(nodes, vtx, idx, rays, nthreads=16, moller_trumbore=True)
+nan_ok = np.isnan(got["uvwt"]) & np.isnan(want["uvwt"])
+d_mt = int(((got["primid"] != want["primid"]) |
+            ((got["uvwt"].view(np.uint32) != want["uvwt"].view(np.uint32)) & ~nan_ok).any(axis=1)).sum())
+print(json.dumps({"case": "the same rays, Moller-Trumbore closest hit", "rays": m, "differing": d_mt}), flush=True)
+bad += d_mt
 sc.close()
+
+# (a3) random triangle soups, several seeds and sizes, host builders in turn
+for k, (tris, builder) in enumerate(((3000, "sah"), (50000, "median"), (200000, "sah"), (20000, "sbvh"))):
+    vtx, idx, _, _ = scenes.random_soup(tris, seed=100 + k)
+    try:
+        nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": builder}))
+    except mipt.MiptError as err:
+        print(json.dumps({"case": f"soup {tris} {builder}", "skipped": str(err)}), flush=True)
+        continue
+    rng = np.random.default_rng(200 + k)
+    rays = np.zeros(min(n, 1 << 20), dtype=mipt.ray_dtype)
+    rays["o"][:, :3] = rng.uniform(-1.5, 1.5, (len(rays), 3))
+    dd = rng.normal(size=(len(rays), 3))
+    rays["d"][:, :3] = dd / np.linalg.norm(dd, axis=1, keepdims=True)
+    rays["o"][:, 3] = np.where(rng.random(len(rays)) < 0.3, rng.uniform(0.01, 2.0, len(rays)), 1e30)
+    sc = mipt.Scene(ctx, nodes, vtx, idx)
+    bad += compare(f"random soup, {tris} triangles, {builder} tree", sc, nodes, vtx, idx, rays, False)
+    d_any = int((sc.trace_any(rays) != oracle.any_hit(nodes, vtx, idx, rays, nthreads=16)).sum())
+    if d_any:
+        print(json.dumps({"case": "  occlusion differs", "differing": d_any}), flush=True)
+    bad += d_any
+    sc.close()
 
 # (b2) occlusion queries on the tie-heavy scene (finite reach, so that some are blocked)
 vtx, idx, _, _ = scenes.atrium(262144, seed=42)
