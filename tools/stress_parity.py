@@ -193,6 +193,36 @@ print(json.dumps({"case": "two-level, awkward rays", "rays": len(rays), "differi
                   "re_resolved": int(st.tie_rays), "hit_fraction": round(float((got["primid"] >= 0).mean()), 3)}), flush=True)
 bad += d + d2
 sc.close()
+# a two-level frame with lamps, glossy material and next-event estimation (the scene of the tests, larger)
+tsc = tl.scene(n_blob_tris=4000, n_blobs=40, seed=9)
+tbuilt = [(mipt.build_bvh(mipt.mesh_leaf_bounds(v, i), opt), v, i, mm) for v, i, mm in tsc["meshes"]]
+ttop = mipt.build_bvh(mipt.instance_bounds(tbuilt, tsc["transforms"], tsc["mesh_of"]), opt)
+tt = oracle.TwoLevel([b[:3] for b in tbuilt], tsc["transforms"], tsc["mesh_of"], ttop)
+sc = mipt.Scene.instanced(ctx, tbuilt, tsc["transforms"], tsc["mesh_of"], ttop, materials=tl.materials(mipt),
+                          material_offsets=tsc["material_offsets"])
+Wt, Ht = 640, 360
+camt = mipt.look_at_camera((0.0, 3.0, -14.0), (0.0, 0.5, 0.0), fovy_deg=45.0, aspect=Wt / Ht)
+filmt = mipt.Film(ctx, Wt, Ht)
+for flags in (0, mipt.PT_RENDER_NEE):
+    filmt.clear()
+    pt_ = mipt.render_params(Wt, Ht, sample_count=4, max_depth=6, seed=5, flags=flags, background=(0.05, 0.06, 0.08))
+    stt = mipt.render(ctx, sc, camt, pt_, filmt, stats=True)
+    wantt, _ = tt.render(tl.materials(oracle), tl.flat_material_ids(tsc), camt, pt_, nthreads=16)
+    dpx = int((filmt.read().view(np.uint32) != wantt.view(np.uint32)).any(axis=-1).sum())
+    print(json.dumps({"case": "two-level frame 640x360, 4 spp, depth 6" + (", next-event estimation" if flags else ""),
+                      "rays": int(stt.rays_primary + stt.rays_bounce + stt.rays_shadow), "differing_pixels": dpx}), flush=True)
+    bad += dpx
+filmt.close()
+sc.close()
+
+# (b5) the reference's camera (depth.frag:47-83) at 3840x2160
+camr = mipt.look_at_camera((0.0, 0.0, -10.0), (0, 0, 0), fovy_deg=60.0, aspect=16 / 9, mode=mipt.PT_CAMERA_REFERENCE)
+gr = ctx.raygen(camr, 3840, 2160)
+ocam = oracle.camera_from(tuple(camr.eye), tuple(camr.c0), tuple(camr.c1), tuple(camr.c2), camr.sx, camr.sy)
+dr = int((gr.view(np.uint32) != oracle.raygen_reference(ocam, 3840, 2160).view(np.uint32)).any(axis=-1).sum()) \
+    if hasattr(oracle, "raygen_reference") else -1
+print(json.dumps({"case": "reference camera rays, 3840x2160", "rays": 3840 * 2160, "differing": dr}), flush=True)
+bad += max(dr, 0)
 
 # (b4) the Cornell box (32 triangles, every surface axis-aligned): awkward rays, and a whole frame
 vtx, idx, mats, mids = scenes.cornell_box()
