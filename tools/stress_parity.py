@@ -53,6 +53,17 @@ for radius, passes in ((0, 16), (8, 4)):
     nodes = sc.read_nodes()
     bad += compare(f"clutter 1 M, GPU tree (radius {radius}, {passes} passes)", sc, nodes, vtx, idx, rays, True)
     sc.close()
+# duplicated triangles in a deep GPU-optimised tree, awkward rays: ties, spills and re-walks together
+idxd = np.concatenate([idx, idx[np.random.default_rng(4).choice(idx.shape[0], idx.shape[0] // 20, replace=False)]])
+raysd = scenes.awkward_rays(vtx, idxd, min(n, 1 << 20), seed=55).astype(mipt.ray_dtype)
+for radius, passes in ((0, 16), (8, 0)):
+    ctx.set_option("build.ploc_radius", radius)
+    ctx.set_option("build.optimize_passes", passes)
+    sc = mipt.Scene(ctx, None, vtx, idxd, link_encoding=mipt.PT_LINKS_INT_BITS)
+    nodes = sc.read_nodes()
+    bad += compare(f"clutter 1 M + 5 % duplicates, GPU tree (radius {radius}, {passes} passes), awkward rays", sc,
+                   nodes, vtx, idxd, raysd, True)
+    sc.close()
 ctx.set_option("build.ploc_radius", 0)
 ctx.set_option("build.optimize_passes", 0)
 
