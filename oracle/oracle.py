@@ -142,6 +142,8 @@ def closest(nodes, vtx, idx, rays, nthreads=1, counters=False, moller_trumbore=F
 
 
 def any_hit(nodes, vtx, idx, rays, nthreads=1) -> np.ndarray:
+    """IntersectSceneAny over a node array with float-valued links (the reference's encoding; the
+    integer-bit encoding is not read here and would be misinterpreted)."""
     nodes, vtx, idx, rays = (_c(nodes, bbox_dtype), _c(vtx, np.float32), _c(idx, np.int32),
                              _c(rays, ray_dtype))
     out = np.zeros(rays.shape[0], dtype=np.int32)

@@ -235,6 +235,45 @@ dr = int((gr.view(np.uint32) != oracle.raygen_reference(ocam, 3840, 2160).view(n
 print(json.dumps({"case": "reference camera rays, 3840x2160", "rays": 3840 * 2160, "differing": dr}), flush=True)
 bad += max(dr, 0)
 
+# (b6) degenerate meshes through the GPU builders: all triangles in one place, zero-area
+# triangles, a planar grid (flat boxes), coordinates spanning twelve orders of magnitude
+rng = np.random.default_rng(77)
+def _mesh(v):
+    v = np.asarray(v, dtype=np.float32).reshape(-1, 3)
+    return v, np.arange(v.shape[0], dtype=np.int32).reshape(-1, 3)
+one = np.tile(np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]), (5000, 1))
+pts = rng.uniform(-1, 1, (30000, 1, 3)).astype(np.float32)
+zero_area = np.concatenate([np.repeat(pts, 3, axis=1).reshape(-1, 3),                       # points
+                            rng.uniform(-1, 1, (30000, 3, 3)).astype(np.float32).reshape(-1, 3)])
+gx, gy = np.meshgrid(np.arange(200, dtype=np.float32), np.arange(200, dtype=np.float32))
+q = np.stack([gx, gy, 0 * gx], -1).reshape(-1, 1, 3)
+plane = np.concatenate([q, q + np.float32([1, 0, 0]), q + np.float32([0, 1, 0])], 1).reshape(-1, 3)
+scale = (10.0 ** rng.uniform(-6, 6, (40000, 1, 1))).astype(np.float32)
+wide = (rng.uniform(-1, 1, (40000, 3, 3)).astype(np.float32) * scale).reshape(-1, 3)
+for label, verts in (("5 000 copies of one triangle", one), ("points and triangles", zero_area),
+                     ("planar grid", plane), ("twelve orders of magnitude", wide)):
+    v, i = _mesh(verts)
+    r = scenes.awkward_rays(v, i, min(n, 1 << 18), seed=5).astype(mipt.ray_dtype)
+    for radius, passes in ((0, 0), (0, 6), (8, 2)):
+        ctx.set_option("build.ploc_radius", radius)
+        ctx.set_option("build.optimize_passes", passes)
+        sc = mipt.Scene(ctx, None, v, i)           # float-valued links: the occlusion restatement reads no others
+        nd = sc.read_nodes()
+        mipt.validate_bvh(nd, i.shape[0], mipt.PT_LINKS_FLOAT_VALUE)
+        got = sc.trace_closest(r)
+        want = oracle.closest(nd, v, i, r, nthreads=16)
+        nan_ok = np.isnan(got["uvwt"]) & np.isnan(want["uvwt"])
+        dd = int(((got["primid"] != want["primid"]) |
+                  ((got["uvwt"].view(np.uint32) != want["uvwt"].view(np.uint32)) & ~nan_ok).any(axis=1)).sum())
+        da = int((sc.trace_any(r) != oracle.any_hit(nd, v, i, r, nthreads=16)).sum())
+        print(json.dumps({"case": f"GPU build of {label} (radius {radius}, {passes} passes)", "rays": len(r),
+                          "differing": dd, "differing_occlusion": da,
+                          "hit_fraction": round(float((got["primid"] >= 0).mean()), 3)}), flush=True)
+        bad += dd + da
+        sc.close()
+ctx.set_option("build.ploc_radius", 0)
+ctx.set_option("build.optimize_passes", 0)
+
 # (b4) the Cornell box (32 triangles, every surface axis-aligned): awkward rays, and a whole frame
 vtx, idx, mats, mids = scenes.cornell_box()
 nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
