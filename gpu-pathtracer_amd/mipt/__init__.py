@@ -198,7 +198,7 @@ for _name, (_res, _args) in _PROTOS.items():
 
 
 def last_error() -> str:
-    return lib.pt_last_error().decode()
+    return lib.pt_last_error().decode(errors="replace")     # messages may quote bytes of a damaged file
 
 
 def _check(rc: int) -> None:
