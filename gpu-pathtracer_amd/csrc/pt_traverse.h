@@ -779,8 +779,8 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     // A ray whose answer may depend on the visiting order is walked again in the reference's
     // fixed order.  That walk is serial and long, so a lane does not start it on the spot with
     // the other 63 waiting: it parks the ray here and goes on, and the parked rays of a wave
-    // are walked side by side once kTieBatch of them have gathered, when a lane has a second
-    // one to park, and at the end of the wave's stream.
+    // are walked side by side once kTieBatch lanes hold one, when a lane with both of its two
+    // places taken has a third to park, and at the end of the wave's stream.
     constexpr int kTieBatch = PT_TIE_BATCH;
     uint32_t parked = kNone, parked2 = kNone;   // two places per lane: batches get larger
     float parked_limit = INFINITY, parked2_limit = INFINITY;   // see traverse_skiplink
