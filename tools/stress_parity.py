@@ -14,6 +14,7 @@ from oracle import oracle
 oracle.build()
 ctx = mipt.Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 21
+OFF = int(os.environ.get("STRESS_SEED", "0"))      # shifts the seeds of every ray set
 
 
 def compare(label, sc, nodes, vtx, idx, rays, int_bits):
@@ -39,13 +40,13 @@ vtx, idx, _, _ = scenes.atrium(262144, seed=42)
 rng = np.random.default_rng(3)
 idx2 = np.concatenate([idx, idx[rng.choice(idx.shape[0], idx.shape[0] // 10, replace=False)]])
 nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx2), mipt.bvh_options(**{"bvh.builder": "sah"}))
-rays = scenes.surface_rays(vtx, idx, n, seed=5).astype(mipt.ray_dtype)
+rays = scenes.surface_rays(vtx, idx, n, seed=5 + OFF).astype(mipt.ray_dtype)
 sc = mipt.Scene(ctx, nodes, vtx, idx2)
 bad += compare("atrium, 10 % duplicated triangles, host SAH tree", sc, nodes, vtx, idx2, rays, False)
 sc.close()
 
 vtx, idx, _, _ = scenes.clutter(1_000_000, seed=11)
-rays = scenes.surface_rays(vtx, idx, n, seed=9).astype(mipt.ray_dtype)
+rays = scenes.surface_rays(vtx, idx, n, seed=9 + OFF).astype(mipt.ray_dtype)
 for radius, passes in ((0, 16), (8, 4)):
     ctx.set_option("build.ploc_radius", radius)
     ctx.set_option("build.optimize_passes", passes)
@@ -55,7 +56,7 @@ for radius, passes in ((0, 16), (8, 4)):
     sc.close()
 # duplicated triangles in a deep GPU-optimised tree, awkward rays: ties, spills and re-walks together
 idxd = np.concatenate([idx, idx[np.random.default_rng(4).choice(idx.shape[0], idx.shape[0] // 20, replace=False)]])
-raysd = scenes.awkward_rays(vtx, idxd, min(n, 1 << 20), seed=55).astype(mipt.ray_dtype)
+raysd = scenes.awkward_rays(vtx, idxd, min(n, 1 << 20), seed=55 + OFF).astype(mipt.ray_dtype)
 for radius, passes in ((0, 16), (8, 0)):
     ctx.set_option("build.ploc_radius", radius)
     ctx.set_option("build.optimize_passes", passes)
@@ -71,7 +72,7 @@ ctx.set_option("build.optimize_passes", 0)
 # structure checked on the host, a sample of rays against the restatement walking that tree
 if len(sys.argv) > 2 and sys.argv[2] == "big":
     vtx, idx, _, _ = scenes.clutter(9_000_000, seed=11)
-    rays = scenes.surface_rays(vtx, idx, 1 << 20, seed=13).astype(mipt.ray_dtype)
+    rays = scenes.surface_rays(vtx, idx, 1 << 20, seed=13 + OFF).astype(mipt.ray_dtype)
     for radius, passes in ((0, 8), (8, 2)):
         ctx.set_option("build.ploc_radius", radius)
         ctx.set_option("build.optimize_passes", passes)
@@ -90,7 +91,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "big":
 vtx, idx, _, _ = scenes.atrium(262144, seed=42)
 nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
 m = min(n, 1 << 21)
-rays = scenes.awkward_rays(vtx, idx, m, seed=21).astype(mipt.ray_dtype)
+rays = scenes.awkward_rays(vtx, idx, m, seed=21 + OFF).astype(mipt.ray_dtype)
 sc = mipt.Scene(ctx, nodes, vtx, idx)
 bad += compare("atrium, awkward rays (axes through vertices, vertex to vertex, on surfaces, far away)", sc, nodes,
                vtx, idx, rays, False)
@@ -133,7 +134,7 @@ for k, (tris, builder) in enumerate(((3000, "sah"), (50000, "median"), (200000, 
 # (b2) occlusion queries on the tie-heavy scene (finite reach, so that some are blocked)
 vtx, idx, _, _ = scenes.atrium(262144, seed=42)
 nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
-rays = scenes.surface_rays(vtx, idx, n, seed=6).astype(mipt.ray_dtype)
+rays = scenes.surface_rays(vtx, idx, n, seed=6 + OFF).astype(mipt.ray_dtype)
 rays["o"][:, 3] = np.random.default_rng(8).uniform(0.05, 6.0, n).astype(np.float32)
 sc = mipt.Scene(ctx, nodes, vtx, idx)
 got = sc.trace_any(rays)
@@ -191,7 +192,7 @@ for k in range(0, tr.shape[0], 7):
     wv.append((v.astype(np.float64) @ tr[k][:, :3].astype(np.float64).T + tr[k][:, 3]).astype(np.float32))
     wi.append(i + off)
     off += v.shape[0]
-rays = scenes.awkward_rays(np.concatenate(wv), np.concatenate(wi), min(n, 1 << 20), seed=33).astype(mipt.ray_dtype)
+rays = scenes.awkward_rays(np.concatenate(wv), np.concatenate(wi), min(n, 1 << 20), seed=33 + OFF).astype(mipt.ray_dtype)
 got, st = sc.trace_closest(rays, stats=True)
 want = t.closest(rays, nthreads=16)
 same = (got["primid"] == want["primid"]) & (got["shapeid"] == want["shapeid"]) & \
@@ -253,7 +254,7 @@ wide = (rng.uniform(-1, 1, (40000, 3, 3)).astype(np.float32) * scale).reshape(-1
 for label, verts in (("5 000 copies of one triangle", one), ("points and triangles", zero_area),
                      ("planar grid", plane), ("twelve orders of magnitude", wide)):
     v, i = _mesh(verts)
-    r = scenes.awkward_rays(v, i, min(n, 1 << 18), seed=5).astype(mipt.ray_dtype)
+    r = scenes.awkward_rays(v, i, min(n, 1 << 18), seed=5 + OFF).astype(mipt.ray_dtype)
     for radius, passes in ((0, 0), (0, 6), (8, 2)):
         ctx.set_option("build.ploc_radius", radius)
         ctx.set_option("build.optimize_passes", passes)
@@ -278,7 +279,7 @@ ctx.set_option("build.optimize_passes", 0)
 vtx, idx, mats, mids = scenes.cornell_box()
 nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
 sc = mipt.Scene(ctx, nodes, vtx, idx, mats, mids)
-rays = scenes.awkward_rays(vtx, idx, min(n, 1 << 20), seed=44).astype(mipt.ray_dtype)
+rays = scenes.awkward_rays(vtx, idx, min(n, 1 << 20), seed=44 + OFF).astype(mipt.ray_dtype)
 bad += compare("Cornell box, awkward rays", sc, nodes, vtx, idx, rays, False)
 d_any = int((sc.trace_any(rays) != oracle.any_hit(nodes, vtx, idx, rays, nthreads=16)).sum())
 Wc, Hc = 960, 540
