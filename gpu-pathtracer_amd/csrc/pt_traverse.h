@@ -784,6 +784,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     constexpr int kTieBatch = PT_TIE_BATCH;
     uint32_t parked = kNone, parked2 = kNone;   // two places per lane: batches get larger
     float parked_limit = INFINITY, parked2_limit = INFINITY;   // see traverse_skiplink
+    float parked_bound = INFINITY, parked2_bound = INFINITY;   // the ordered hit, widened by the window
     auto walk_parked = [&]() {
         while (parked != kNone) {
             int32_t shapeid, primid;
@@ -793,9 +794,16 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
             const float4 rd = reinterpret_cast<const float4 *>(rays + parked)[1];
             traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt,
                                             parked_limit);
+            // The bounded walk starts from a hit the ordered traversal has found, so it must come
+            // back with one at most the tie window beyond it.  If it does not, the rounding
+            // margin in its starting distance was too small for this ray after all: the walk is
+            // repeated from the ray's own reach, which is the reference's loop as written.
+            if (parked_limit < INFINITY && (primid < 0 || !(t <= parked_bound)))
+                traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt);
             if constexpr (!ANY) sink(parked, shapeid, primid, b0, b1, b2, t);
             parked = parked2;
             parked_limit = parked2_limit;
+            parked_bound = parked2_bound;
             parked2 = kNone;
         }
     };
@@ -823,8 +831,9 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                 if (tie && fixup) {
                     // a complete search's nearest hit bounds the answer; one cut short by a
                     // non-finite value or a full stack does not
-                    float lim = INFINITY;
+                    float lim = INFINITY, lim_bound = INFINITY;
                     if (!st.tie && st.primid >= 0) {
+                        lim_bound = st.tbest + st.tbest * PT_TIE_WINDOW;
                         // The walk must enter every box on the way to that hit.  A box's computed
                         // entry distance can lie past the computed hit distance by rounding (a flat
                         // triangle's box has no depth): by a few units in the last place of the
@@ -834,14 +843,16 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                         const float ex = (fabsf(st.r.ox) + fmaxf(fabsf(lo.x), fabsf(hi.x))) * fabsf(st.r.ix);
                         const float ey = (fabsf(st.r.oy) + fmaxf(fabsf(lo.y), fabsf(hi.y))) * fabsf(st.r.iy);
                         const float ez = (fabsf(st.r.oz) + fmaxf(fabsf(lo.z), fabsf(hi.z))) * fabsf(st.r.iz);
-                        lim = (st.tbest + st.tbest * PT_TIE_WINDOW) + 3.814697265625e-06f * fmaxf(ex, fmaxf(ey, ez));
+                        lim = lim_bound + 3.814697265625e-06f * fmaxf(ex, fmaxf(ey, ez));
                     }
                     if (parked == kNone) {
                         parked = my_ray;
                         parked_limit = lim;
+                        parked_bound = lim_bound;
                     } else {
                         parked2 = my_ray;
                         parked2_limit = lim;
+                        parked2_bound = lim_bound;
                     }
                 } else
                     sink(my_ray, st.primid >= 0 ? 0 : -1, st.primid, st.b0, st.b1, st.b2, st.tbest);
