@@ -273,6 +273,9 @@ int pt_context_create(int device, pt_context **out) {
     if (ctx->stack_spill.reserve((size_t)ctx->num_cus * kMaxBlocksPerCu * PT_TRACE_BLOCK *
                                  kSpillEntries * sizeof(int32_t)) != PT_OK)
         (void)hipGetLastError();
+    // this device's address of the static scratch array of pt_trace_closest_device_static
+    const int src = static_scratch_init(device);
+    if (src != PT_OK) return src;
     *out = ctx.release();
     return PT_OK;
     PT_CATCH
@@ -626,8 +629,8 @@ int pt_scene_destroy(pt_scene *scene) {
 static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_ray *rays_dev,
                               uint64_t n, pt_hit *hits_dev, uint32_t flags, bool count,
                               pt_trace_stats *stats) {
-    if (n > 0xFFFFFFF0ull)
-        return fail(PT_ERR_INVALID, "pt_trace_closest: more than 2^32-16 rays in one call");
+    if (n > PT_TRACE_MAX_RAYS)
+        return fail(PT_ERR_INVALID, "pt_trace_closest: more than 2^31-64 rays in one call");
     HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool exact = (flags & (PT_TRACE_EXACT_ORDER | PT_TRACE_MOLLER_TRUMBORE)) != 0;
@@ -676,6 +679,27 @@ int pt_trace_closest_device(pt_context *ctx, const pt_scene *scene, const pt_ray
     PT_CATCH
 }
 
+int pt_trace_closest_device_static(pt_context *ctx, const pt_scene *scene, const pt_ray *rays_dev,
+                                   uint64_t n, pt_hit *hits_dev, uint32_t flags) {
+    if (!ctx || !scene || (n && (!rays_dev || !hits_dev)))
+        return fail(PT_ERR_INVALID, "pt_trace_closest_device_static: null argument");
+    if (scene->ctx != ctx) return fail(PT_ERR_INVALID, "scene belongs to another context");
+    if (n > PT_TRACE_MAX_RAYS)
+        return fail(PT_ERR_INVALID, "pt_trace_closest_device_static: " + std::to_string(n) +
+                                        " rays exceed the maximum of 2^31-64 per call");
+    if ((flags & PT_TRACE_MOLLER_TRUMBORE) && scene->dev.tlas)
+        return fail(PT_ERR_UNSUPPORTED, "pt_trace_closest_device_static: PT_TRACE_MOLLER_TRUMBORE "
+                                        "is not available on two-level scenes");
+    PT_TRY
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const int rc = launch_trace_static(ctx->stream, ctx->device, scene->dev, rays_dev, hits_dev, n,
+                                       flags, ctx->extend_config());
+    if (rc != PT_OK) return rc;
+    HIP_CHECK(hipGetLastError());
+    return PT_OK;
+    PT_CATCH
+}
+
 int pt_trace_closest_device_counted(pt_context *ctx, const pt_scene *scene,
                                     const pt_ray *rays_dev, uint64_t n, pt_hit *hits_dev,
                                     uint32_t flags, pt_trace_stats *stats) {
@@ -720,8 +744,8 @@ int pt_trace_any_device(pt_context *ctx, const pt_scene *scene, const pt_ray *ra
         return fail(PT_ERR_INVALID, "pt_trace_any_device: null argument");
     if (scene->ctx != ctx) return fail(PT_ERR_INVALID, "scene belongs to another context");
     HIP_CHECK(hipSetDevice(ctx->device));
-    if (n > 0xFFFFFFF0ull)
-        return fail(PT_ERR_INVALID, "pt_trace_any: more than 2^32-16 rays in one call");
+    if (n > PT_TRACE_MAX_RAYS)
+        return fail(PT_ERR_INVALID, "pt_trace_any: more than 2^31-64 rays in one call");
     launch_trace_any(ctx->stream, scene->dev, rays_dev, occluded_dev, n, ctx->any_exact_order != 0,
                      ctx->extend_config());
     HIP_CHECK(hipGetLastError());
@@ -734,8 +758,8 @@ int pt_trace_any(pt_context *ctx, const pt_scene *scene, const pt_ray *rays, uin
         return fail(PT_ERR_INVALID, "pt_trace_any: null argument");
     if (scene->ctx != ctx) return fail(PT_ERR_INVALID, "scene belongs to another context");
     if (n == 0) return PT_OK;
-    if (n > 0xFFFFFFF0ull)
-        return fail(PT_ERR_INVALID, "pt_trace_any: more than 2^32-16 rays in one call");
+    if (n > PT_TRACE_MAX_RAYS)
+        return fail(PT_ERR_INVALID, "pt_trace_any: more than 2^31-64 rays in one call");
     HIP_CHECK(hipSetDevice(ctx->device));
     int rc = ctx->io_rays.reserve(sizeof(pt_ray) * n);
     if (rc != PT_OK) return rc;

@@ -59,6 +59,7 @@ struct pt_context {
         c.sort_rays = 0;
         c.spill = (int32_t *)stack_spill.ptr;
         c.spill_entries = stack_spill.ptr ? mipt::kSpillEntries : 0;
+        c.max_grid = 0;
         return c;
     }
 

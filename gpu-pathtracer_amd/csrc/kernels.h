@@ -74,6 +74,9 @@ struct ExtendConfig {
     // holds, spill_entries slots for each lane of the largest grid (kSpillEntries, or 0)
     int32_t *spill;
     int spill_entries;
+    // persistent form: upper bound on the grid in workgroups (0: none), for a spill area that
+    // was sized for fewer lanes than the device could keep resident
+    unsigned int max_grid;
 };
 
 // Stack entries per lane beyond the LDS ones: a ray stays in the voted loop up to about
@@ -120,6 +123,19 @@ unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &
 // two-child nodes, nearer child first (the answer is the same).
 void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, int32_t *occluded,
                       uint64_t n, bool exact_order, const ExtendConfig &cfg);
+
+// The closest-hit query with every byte of device memory it needs beyond the caller's rays and
+// hits taken from one file-scope device array (work counters and the stack-spill slots), so
+// that the call allocates nothing.  static_scratch_init: once per device, with that device
+// current, before the first launch there; it resolves the array's address on that device.
+constexpr int kStaticSpillEntries = 16;          // global stack slots per lane in this form
+constexpr unsigned int kStaticMaxGrid = 1280;    // persistent workgroups the slots are sized for
+constexpr size_t kStaticCounterBytes = 256;
+constexpr size_t kStaticScratchBytes =
+    kStaticCounterBytes + (size_t)kStaticMaxGrid * PT_TRACE_BLOCK * kStaticSpillEntries * sizeof(int32_t);
+int static_scratch_init(int device);
+int launch_trace_static(hipStream_t st, int device, const DeviceScene &s, const pt_ray *rays,
+                        pt_hit *hits, uint64_t n, uint32_t flags, ExtendConfig cfg);
 
 void launch_raygen(hipStream_t st, const pt_camera &cam, uint32_t width, uint32_t height,
                    pt_ray *rays);

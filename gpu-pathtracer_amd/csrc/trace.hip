@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <string>
 
 namespace mipt {
 
@@ -216,7 +217,8 @@ unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &
         per_cu = (e == hipSuccess && nb > 0) ? nb : 4;
         cache->store(per_cu, std::memory_order_relaxed);
     }
-    return (unsigned int)(cfg.num_cus * std::min(per_cu, cfg.blocks_per_cu));
+    const unsigned int grid = (unsigned int)(cfg.num_cus * std::min(per_cu, cfg.blocks_per_cu));
+    return cfg.max_grid ? std::min(grid, cfg.max_grid) : grid;
 }
 
 void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
@@ -350,6 +352,58 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
     }
     hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays, occluded, n,
                        wide);
+}
+
+// ---- the closest-hit query without any allocation ----------------------------------------
+// Everything the kernels above need beyond the caller's rays and hits -- the counter block and
+// the global slots behind the LDS stacks -- lies in this array, which every GPU the library
+// runs on holds for the life of the process.  In host code `scratch` is only a handle for
+// hipGetSymbolAddress; the address on each device is looked up once (static_scratch_init) and
+// that pointer is what memsets and kernel arguments use.
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+void *g_scratch_ptr[kMaxDevices];       // per device: that device's copy of `scratch`
+std::atomic<bool> g_scratch_known[kMaxDevices];
+}
+
+int static_scratch_init(int device) {
+    if (device < 0 || device >= kMaxDevices)
+        return fail(PT_ERR_UNSUPPORTED, "static scratch: device index beyond " + std::to_string(kMaxDevices));
+    if (g_scratch_known[device].load(std::memory_order_acquire)) return PT_OK;
+    void *ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) return hip_fail(e, "hipGetSymbolAddress(scratch)");
+    g_scratch_ptr[device] = ptr;        // contexts racing here store the same value
+    g_scratch_known[device].store(true, std::memory_order_release);
+    return PT_OK;
+}
+
+int launch_trace_static(hipStream_t st, int device, const DeviceScene &s, const pt_ray *rays,
+                        pt_hit *hits, uint64_t n, uint32_t flags, ExtendConfig cfg) {
+    if (device < 0 || device >= kMaxDevices || !g_scratch_known[device].load(std::memory_order_acquire))
+        return fail(PT_ERR_DEVICE, "static scratch of this device was not initialised");
+    unsigned char *base = (unsigned char *)g_scratch_ptr[device];
+    DeviceTraceCounters *counters = (DeviceTraceCounters *)base;
+    static_assert(sizeof(DeviceTraceCounters) <= kStaticCounterBytes, "counter block");
+    // the array keeps the last call's contents: the counters must start at zero, the stack
+    // slots are written before they are read
+    const hipError_t e = hipMemsetAsync(counters, 0, sizeof(DeviceTraceCounters), st);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(static counters)");
+    cfg.spill = (int32_t *)(base + kStaticCounterBytes);
+    cfg.spill_entries = kStaticSpillEntries;
+    cfg.max_grid = kStaticMaxGrid;
+    cfg.sort_rays = 0;                  // a sorted call needs room in proportion to n
+    const bool exact = (flags & (PT_TRACE_EXACT_ORDER | PT_TRACE_MOLLER_TRUMBORE)) != 0;
+    const bool fixup = (flags & PT_TRACE_NO_TIE_FIXUP) == 0;
+    if (s.tlas)
+        launch_trace_two_level(st, s, rays, hits, n, fixup, exact, counters, false, cfg);
+    else if (exact)
+        launch_trace_skiplink(st, s, rays, hits, n, (flags & PT_TRACE_MOLLER_TRUMBORE) != 0, nullptr);
+    else
+        launch_trace_ordered(st, s, rays, hits, n, fixup, counters, false, cfg, nullptr);
+    return PT_OK;
 }
 
 } // namespace mipt

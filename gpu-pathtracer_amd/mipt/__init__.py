@@ -163,6 +163,7 @@ _PROTOS = {
     "pt_trace_closest": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32,
                                    C.POINTER(TraceStats)]),
     "pt_trace_closest_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32]),
+    "pt_trace_closest_device_static": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32]),
     "pt_trace_closest_device_counted": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32,
                                                   C.POINTER(TraceStats)]),
     "pt_trace_any": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
@@ -516,6 +517,11 @@ class Scene:
     def trace_closest_device(self, rays_dev: int, n: int, hits_dev: int,
                              flags: int = PT_TRACE_DEFAULT) -> None:
         _check(lib.pt_trace_closest_device(self.ctx._h, self._h, rays_dev, n, hits_dev, flags))
+
+    def trace_closest_device_static(self, rays_dev: int, n: int, hits_dev: int,
+                                    flags: int = PT_TRACE_DEFAULT) -> None:
+        """``pt_trace_closest_device`` without any device allocation (static scratch)."""
+        _check(lib.pt_trace_closest_device_static(self.ctx._h, self._h, rays_dev, n, hits_dev, flags))
 
     def trace_closest_device_counted(self, rays_dev: int, n: int, hits_dev: int,
                                      flags: int = PT_TRACE_DEFAULT) -> TraceStats:

@@ -297,6 +297,8 @@ uint32_t pt_scene_link_encoding(const pt_scene *scene);
 int pt_scene_read_nodes(pt_scene *scene, pt_bbox *nodes);
 int pt_scene_destroy(pt_scene *scene);
 
+/* Most rays one pt_trace_* call takes. */
+#define PT_TRACE_MAX_RAYS 0x7FFFFFC0ull   /* 2^31 - 64 */
 /* IntersectSceneClosest, shaders/RadeonRays/bvh.glslh:417-456, for n rays.
  * flags: PT_TRACE_*.  stats may be NULL. */
 int pt_trace_closest(pt_context *ctx, const pt_scene *scene, const pt_ray *rays, uint64_t n,
@@ -308,6 +310,21 @@ int pt_trace_closest_device(pt_context *ctx, const pt_scene *scene, const pt_ray
 int pt_trace_closest_device_counted(pt_context *ctx, const pt_scene *scene,
                                     const pt_ray *rays_dev, uint64_t n, pt_hit *hits_dev,
                                     uint32_t flags, pt_trace_stats *stats);
+
+/* pt_trace_closest_device for callers that cannot allocate device memory (code under HIP
+ * graph capture, serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same hits, bit for bit; what the kernels need beyond rays_dev and hits_dev (a
+ * counter block and the global slots behind the per-lane LDS stacks) lies in a static device
+ * array of PT_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process
+ * ends, and the call makes no hipMalloc / hipFree.  For that the persistent grid is limited
+ * to 1280 workgroups with 16 global stack slots per lane (a ray with more than 46 pending
+ * nodes takes the fixed-order walk: slower, same answer) and the rays are always taken in
+ * queue order (option "trace.sort_rays" is ignored).  Fails with PT_ERR_INVALID above
+ * PT_TRACE_MAX_RAYS rays.  All calls on one GPU share the array: calls that overlap on one
+ * GPU (two contexts or two streams) race and must be serialised by the caller. */
+#define PT_STATIC_SCRATCH_BYTES (256u + 1280u * 256u * 16u * 4u)
+int pt_trace_closest_device_static(pt_context *ctx, const pt_scene *scene, const pt_ray *rays_dev,
+                                   uint64_t n, pt_hit *hits_dev, uint32_t flags);
 
 /* IntersectSceneAny, shaders/RadeonRays/bvh.glslh:378-414: occluded[i] = 1 or 0. */
 int pt_trace_any(pt_context *ctx, const pt_scene *scene, const pt_ray *rays, uint64_t n,
