@@ -40,6 +40,41 @@ struct FileCloser {
 };
 using File = std::unique_ptr<FILE, FileCloser>;
 
+// Writes header + payload to path + ".tmp" and renames it over path once everything, the close
+// included, has succeeded: an interrupted or failed save leaves the previous file as it was.
+int write_file_atomically(const char *who, const char *path, const void *header, size_t header_bytes,
+                          const void *payload, size_t payload_bytes) {
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return fail(PT_ERR_IO, std::string(who) + ": cannot open " + tmp);
+    bool ok = std::fwrite(header, header_bytes, 1, f) == 1 &&
+              (payload_bytes == 0 || std::fwrite(payload, payload_bytes, 1, f) == 1) &&
+              std::fflush(f) == 0;
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) {
+        std::remove(tmp.c_str());
+        return fail(PT_ERR_IO, std::string(who) + ": short write to " + tmp);
+    }
+    if (std::rename(tmp.c_str(), path) != 0) {
+        std::remove(tmp.c_str());
+        return fail(PT_ERR_IO, std::string(who) + ": cannot rename " + tmp + " to " + path);
+    }
+    return PT_OK;
+}
+
+// Bytes left in the file from the current position, or -1.
+long long bytes_left(FILE *f) {
+    const long here = std::ftell(f);
+    if (here < 0 || std::fseek(f, 0, SEEK_END) != 0) return -1;
+    const long end = std::ftell(f);
+    if (end < 0 || std::fseek(f, here, SEEK_SET) != 0) return -1;
+    return (long long)end - here;
+}
+
+// Bumped whenever the host builder, its optimiser or the leaf-box inflation change what they
+// produce from the same inputs, so that trees cached by an older library are rebuilt.
+constexpr uint64_t kBuilderRevision = 2;
+
 struct BvhFileHeader {
     char magic[8];            // "MIPTBVH1"
     uint32_t link_encoding;
@@ -60,24 +95,35 @@ extern "C" {
 
 uint64_t pt_bvh_cache_key(const pt_bbox *leaf_bounds, uint32_t n_leaves, const pt_bvh_options *opt) {
     uint64_t h = fnv1a(leaf_bounds, leaf_bounds ? sizeof(pt_bbox) * (size_t)n_leaves : 0);
-    if (opt) h = fnv1a(opt, sizeof(*opt), h);
+    if (opt) {
+        // only what determines the tree: num_threads does not
+        pt_bvh_options o;
+        std::memset(&o, 0, sizeof(o));
+        o.use_sah = opt->use_sah;
+        o.use_splits = opt->use_splits;
+        o.max_split_depth = opt->max_split_depth;
+        o.num_bins = opt->num_bins;
+        o.min_overlap = opt->min_overlap;
+        o.traversal_cost = opt->traversal_cost;
+        o.extra_node_budget = opt->extra_node_budget;
+        o.link_encoding = opt->link_encoding;
+        o.optimize_passes = opt->optimize_passes;
+        h = fnv1a(&o, sizeof(o), h);
+    }
+    h = fnv1a(&kBuilderRevision, sizeof(kBuilderRevision), h);
     return fnv1a(&n_leaves, sizeof(n_leaves), h);
 }
 
 int pt_bvh_save(const pt_bvh *bvh, const char *path, uint64_t key) {
     if (!bvh || !path) return fail(PT_ERR_INVALID, "pt_bvh_save: null argument");
-    File f(std::fopen(path, "wb"));
-    if (!f) return fail(PT_ERR_IO, std::string("pt_bvh_save: cannot open ") + path);
     BvhFileHeader h{};
     std::memcpy(h.magic, "MIPTBVH1", 8);
     h.link_encoding = bvh->link_encoding;
     h.n_nodes = (uint32_t)bvh->nodes.size();
     h.key = key;
     h.payload_hash = fnv1a(bvh->nodes.data(), sizeof(pt_bbox) * bvh->nodes.size());
-    if (std::fwrite(&h, sizeof(h), 1, f.get()) != 1 ||
-        std::fwrite(bvh->nodes.data(), sizeof(pt_bbox), bvh->nodes.size(), f.get()) != bvh->nodes.size())
-        return fail(PT_ERR_IO, std::string("pt_bvh_save: short write to ") + path);
-    return PT_OK;
+    return write_file_atomically("pt_bvh_save", path, &h, sizeof(h), bvh->nodes.data(),
+                                 sizeof(pt_bbox) * bvh->nodes.size());
 }
 
 int pt_bvh_load(const char *path, uint64_t key, pt_bvh **out) {
@@ -91,6 +137,10 @@ int pt_bvh_load(const char *path, uint64_t key, pt_bvh **out) {
     if (h.key != key) return fail(PT_ERR_STALE, "pt_bvh_load: cache was built from other inputs");
     if (h.n_nodes == 0 || (h.link_encoding != PT_LINKS_FLOAT_VALUE && h.link_encoding != PT_LINKS_INT_BITS))
         return fail(PT_ERR_IO, "pt_bvh_load: corrupt header");
+    // a skip-link array has 2n-1 nodes, and the file must hold exactly what the header announces
+    // (checked before anything of that size is allocated)
+    if (h.n_nodes % 2 == 0 || bytes_left(f.get()) != (long long)sizeof(pt_bbox) * h.n_nodes)
+        return fail(PT_ERR_IO, "pt_bvh_load: header and file size disagree");
     try {
         auto b = std::make_unique<pt_bvh>();
         b->link_encoding = h.link_encoding;
@@ -116,17 +166,13 @@ int pt_film_save(pt_film *film, const char *path) {
     }
     int rc = pt_film_read(film, px.data());
     if (rc != PT_OK) return rc;
-    File f(std::fopen(path, "wb"));
-    if (!f) return fail(PT_ERR_IO, std::string("pt_film_save: cannot open ") + path);
     FilmFileHeader h{};
     std::memcpy(h.magic, "MIPTFLM1", 8);
     h.width = film->width;
     h.height = film->height;
     h.payload_hash = fnv1a(px.data(), px.size() * sizeof(float));
-    if (std::fwrite(&h, sizeof(h), 1, f.get()) != 1 ||
-        std::fwrite(px.data(), sizeof(float), px.size(), f.get()) != px.size())
-        return fail(PT_ERR_IO, std::string("pt_film_save: short write to ") + path);
-    return PT_OK;
+    return write_file_atomically("pt_film_save", path, &h, sizeof(h), px.data(),
+                                 px.size() * sizeof(float));
 }
 
 int pt_film_load(pt_film *film, const char *path) {

@@ -279,7 +279,15 @@ struct Gltf {
         const Json &a = at("accessors", accessor);
         if (a.get("sparse")) throw std::runtime_error("sparse accessors are not supported");
         const long ct = a.index("componentType");
-        const size_t count = (size_t)a.number("count", 0);
+        // Sizes and offsets are JSON numbers (doubles): only non-negative integers that a double
+        // holds exactly are taken, so that no cast or sum below can wrap.
+        auto size_field = [](const Json &j, const char *key) -> size_t {
+            const double v = j.number(key, 0);
+            if (!(v >= 0.0) || v > 9007199254740992.0 || v != std::floor(v))
+                throw std::runtime_error(std::string(key) + " is not a non-negative integer");
+            return (size_t)v;
+        };
+        const size_t count = size_field(a, "count");
         const Json *ty = a.get("type");
         const std::string type = ty ? ty->str : "";
         const int comps = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : 0;
@@ -289,13 +297,23 @@ struct Gltf {
         const Json &bv = at("bufferViews", a.index("bufferView"));
         const long b = bv.index("buffer");
         if (b < 0 || (size_t)b >= buffers.size()) throw std::runtime_error("bufferView.buffer out of range");
-        const size_t off = (size_t)bv.number("byteOffset", 0) + (size_t)a.number("byteOffset", 0);
-        size_t stride = (size_t)bv.number("byteStride", 0);
-        if (!stride) stride = csize * comps;
-        const size_t need = count ? off + (count - 1) * stride + csize * comps : off;
-        if (need > buffers[(size_t)b].size() ||
-            (size_t)bv.number("byteOffset", 0) + (size_t)bv.number("byteLength", 0) > buffers[(size_t)b].size())
-            throw std::runtime_error("accessor reaches beyond its buffer");
+        const size_t buf_size = buffers[(size_t)b].size();
+        const size_t view_off = size_field(bv, "byteOffset"), view_len = size_field(bv, "byteLength");
+        const size_t acc_off = size_field(a, "byteOffset");
+        const size_t elem = csize * (size_t)comps;
+        size_t stride = size_field(bv, "byteStride");
+        if (!stride) stride = elem;
+        // the view lies inside its buffer, the accessor's elements inside the view
+        if (view_off > buf_size || view_len > buf_size - view_off)
+            throw std::runtime_error("bufferView reaches beyond its buffer");
+        if (count) {
+            if (acc_off > view_len || elem > view_len - acc_off ||
+                count - 1 > (view_len - acc_off - elem) / stride)
+                throw std::runtime_error("accessor reaches beyond its bufferView");
+        } else if (acc_off > view_len) {
+            throw std::runtime_error("accessor reaches beyond its bufferView");
+        }
+        const size_t off = view_off + acc_off;
         return View{buffers[(size_t)b].data() + off, stride, count, ct, comps};
     }
 

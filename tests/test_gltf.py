@@ -129,6 +129,45 @@ def test_gltf_errors(mipt, tmp_path):
         mipt.Mesh(path)
 
 
+@pytest.mark.parametrize("field,where,value,message", [
+    # sizes chosen so that count * stride, or the sum of the offsets, wraps 64-bit arithmetic
+    ("count", ("accessors", 1), 2 ** 62, "non-negative integer"),       # beyond what a double holds exactly
+    ("count", ("accessors", 1), 2 ** 52, "beyond its buffer"),
+    ("count", ("accessors", 1), 2 ** 63 + 3, "non-negative integer"),
+    ("count", ("accessors", 0), 2 ** 52 + 1, "beyond its buffer"),
+    ("count", ("accessors", 1), -6, "non-negative integer"),
+    ("count", ("accessors", 1), 5.5, "non-negative integer"),
+    ("byteOffset", ("accessors", 1), 2 ** 64 - 4, "non-negative integer"),
+    ("byteOffset", ("accessors", 1), 2 ** 53, "beyond its buffer"),
+    ("byteOffset", ("accessors", 1), -2, "non-negative integer"),
+    ("byteOffset", ("bufferViews", 1), 2 ** 53, "beyond its buffer"),
+    ("byteOffset", ("bufferViews", 1), -80, "non-negative integer"),
+    ("byteLength", ("bufferViews", 1), 2 ** 53, "beyond its buffer"),
+    ("byteStride", ("bufferViews", 0), 2 ** 52, "beyond its buffer"),
+    ("byteStride", ("bufferViews", 0), -20, "non-negative integer"),
+    # the accessor must stay inside its bufferView even where the buffer goes on
+    ("count", ("accessors", 1), 7, "beyond its buffer"),
+])
+def test_gltf_accessor_sizes_cannot_overflow(mipt, tmp_path, field, where, value, message):
+    path, *_ = _document(tmp_path, "external")
+    doc = json.loads(open(path).read())
+    doc[where[0]][where[1]][field] = value
+    open(path, "w").write(json.dumps(doc))
+    with pytest.raises(mipt.MiptError, match=message):
+        mipt.Mesh(path)
+
+
+def test_gltf_count_times_stride_cannot_wrap(mipt, tmp_path):
+    """count and byteStride each acceptable, their product beyond 2^64."""
+    path, *_ = _document(tmp_path, "external")
+    doc = json.loads(open(path).read())
+    doc["accessors"][0]["count"] = 2 ** 40 + 1
+    doc["bufferViews"][0]["byteStride"] = 2 ** 24 * 20        # (count - 1) * stride = 20 * 2^64
+    open(path, "w").write(json.dumps(doc))
+    with pytest.raises(mipt.MiptError, match="beyond its buffer"):
+        mipt.Mesh(path)
+
+
 def _instanced_document(tmp_path):
     """One quad mesh shown by three nodes (one of them nested), one triangle mesh shown once,
     and a mesh no node shows."""

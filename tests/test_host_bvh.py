@@ -213,6 +213,31 @@ def test_bvh_cache_round_trip(mipt, scenes, tmp_path):
     d, cached = mipt.build_bvh_cached(lb, path, mipt.bvh_options(**{"bvh.builder": "median"}))
     assert not cached
     np.testing.assert_array_equal(c.view(np.uint32), d.view(np.uint32))
+    # the thread count does not change the tree, so it does not change the key
+    e, cached = mipt.build_bvh_cached(lb, path, mipt.bvh_options(**{"bvh.builder": "median",
+                                                                    "mipt.num_threads": "3"}))
+    assert cached
+    # a header announcing more nodes than the file holds is refused before anything is allocated
+    import os
+    import struct
+    raw = bytearray(open(path, "rb").read())
+    raw[12:16] = struct.pack("<I", 0xFFFFFFFF)
+    open(path, "wb").write(bytes(raw))
+    h = mipt.C.c_void_p()
+    key = mipt.lib.pt_bvh_cache_key(lb.ctypes.data, lb.shape[0], None)
+    struct.pack_into("<Q", raw, 16, key)
+    open(path, "wb").write(bytes(raw))
+    assert mipt.lib.pt_bvh_load(path.encode(), key, mipt.C.byref(h)) == mipt.PT_ERR_IO
+    assert "file size" in mipt.last_error()
+    # saves go through a temporary file: none is left behind, and a save that cannot be made
+    # leaves the target as it was
+    f, cached = mipt.build_bvh_cached(lb, path, opt)
+    assert not cached and not os.path.exists(path + ".tmp")
+    good = open(path, "rb").read()
+    os.mkdir(path + ".tmp")                       # the temporary name is taken by a directory
+    with pytest.raises(mipt.MiptError):
+        mipt.build_bvh_cached(lb, path, mipt.bvh_options(**{"bvh.builder": "median"}))
+    assert open(path, "rb").read() == good
 
 
 def _sliver_scene(scenes, n=1500, seed=13):
