@@ -3,16 +3,19 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (the configuration the headline metric is quoted on): Sponza-class
-scene (262,144-triangle procedural stand-in for Crytek Sponza, seed 42 -- no assets exist
-offline), 1920x1080, Lambert+GGX materials, max depth 8, Russian roulette from bounce 3.
-A step is one pass of the whole hot path -- raygen, (extend, shade) x depth, accumulate --
-over one batch of --spp-per-step samples per pixel; 256 spp is 256/spp-per-step steps.
+Workload (the configuration the headline metric is quoted on): Sponza-class scene
+(262,144-triangle procedural stand-in for Crytek Sponza, seed 42 -- no assets exist offline;
+`--scene FILE` or `PT_SCENE_DIR` holding sponza.obj / sponza.glb renders the real asset
+instead), 1920x1080, Lambert+GGX materials, max depth 8, Russian roulette from bounce 3.
+A step is one pass of the whole hot path -- raygen, (extend, shade) x depth, accumulate -- over
+--spp-per-step samples per pixel of the frame; the default 20 steps of 16 spp are 320 spp.
 Scene, BVH and film are resident in HBM before the timed region.
 
-Multi-GPU: one process per GPU, scene replicated, ranks render disjoint sample ranges of the
-same frame (weak scaling: work per rank fixed) with no collective on the data path; the film
-is summed once over RCCL (reduce to rank 0) at the end of the timed region.
+Multi-GPU: one process per GPU, scene replicated, no collective on the data path.  Default is
+strong scaling: the same frame (same total samples per step) is split over the ranks, by
+sample ranges or by 64x64 tiles, and assembled once over RCCL at the end of the timed region
+through the library's C ABI (pt_film_reduce / pt_film_gather_tiles), so value = rays of the
+frame / time to the assembled frame.  --scaling weak keeps the work per rank fixed instead.
 
 Prints one JSON line (rank 0): value = rays traced by all ranks / wall time, in Mrays/s.
 """
@@ -29,19 +32,29 @@ for _p in (os.path.join(REPO, "gpu-pathtracer_amd"), REPO):
 
 import numpy as np  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tris", type=int, default=262144)
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--spp-per-step", type=int, default=4)
+    ap.add_argument("--spp-per-step", type=int, default=16,
+                    help="samples per pixel of one step (of the whole frame with --scaling strong, "
+                         "of each rank with --scaling weak)")
+    ap.add_argument("--samples-per-pass", type=int, default=0,
+                    help="pt_render_params.samples_per_pass (0: library default)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--sharding", choices=["samples", "tiles"], default="samples",
                     help="how N ranks split the frame (N > 1)")
+    ap.add_argument("--assembly", choices=["abi", "torch"], default="abi",
+                    help="frame assembly through the library's RCCL entry points or torch.distributed")
+    ap.add_argument("--scene", default=None, help="OBJ / glTF / GLB file to render instead of the stand-in")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=INT",
                     help="pt_context_set_option tuning knob, e.g. extend.persistent=0")
     ap.add_argument("--bvh-option", action="append", default=[], metavar="KEY=VALUE",
@@ -49,9 +62,52 @@ def parse_args():
     ap.add_argument("--nee", action="store_true",
                     help="next-event estimation: one shadow ray per path vertex (counted in value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-record", action="store_true",
+                    help="skip the second roofline record (28 M-triangle scene, HBM-resident traversal)")
+    ap.add_argument("--hbm-tris", type=int, default=28_000_000)
+    ap.add_argument("--hbm-rays", type=int, default=1 << 24)
     ap.add_argument("--cpu-baseline-scale", type=int, default=1,
                     help="the CPU baseline renders the frame at 1/scale resolution in x and y")
     return ap.parse_args()
+
+
+def find_scene_file(args):
+    """--scene, or the Sponza asset in PT_SCENE_DIR if there is one."""
+    if args.scene:
+        return args.scene
+    d = os.environ.get("PT_SCENE_DIR")
+    if d:
+        for name in ("sponza.obj", "sponza.glb", "sponza.gltf", "Sponza.obj", "Sponza.glb", "Sponza.gltf"):
+            p = os.path.join(d, name)
+            if os.path.exists(p):
+                return p
+    return None
+
+
+def load_workload(args, mipt, scenes):
+    """(vtx, idx, materials, material_ids, camera factory, description, data)."""
+    path = find_scene_file(args)
+    if path is None:
+        vtx, idx, mats, mids = scenes.atrium(args.tris, seed=42)
+        return (vtx, idx, mats, mids, scenes.atrium_camera,
+                "Sponza-class atrium stand-in (%d tris, seed 42)" % idx.shape[0], "synthetic")
+    # the fields the reference takes from its loader (src/main.cpp:852-899,
+    # src/main_granite.cpp:265-298), through pt_obj_load / pt_gltf_load
+    m = mipt.Mesh(path)
+    lo, hi = m.vtx.min(axis=0), m.vtx.max(axis=0)
+    centre, ext = (lo + hi) / 2, (hi - lo)
+    axis = int(np.argmax(ext[[0, 2]])) * 2                    # look along the longer floor axis
+    eye = centre.copy()
+    eye[axis] -= 0.35 * ext[axis]
+    eye[1] = lo[1] + 0.3 * ext[1]
+    target = centre.copy()
+    target[1] = lo[1] + 0.35 * ext[1]
+
+    def camera(aspect):
+        return mipt.look_at_camera(tuple(eye), tuple(target), fovy_deg=55.0, aspect=aspect)
+    mats, mids = (m.materials, m.material_ids) if len(m.materials) else (None, None)
+    return (m.vtx, m.idx, mats, mids, camera,
+            "%s (%d tris)" % (os.path.basename(path), m.idx.shape[0]), "file")
 
 
 def main():
@@ -60,6 +116,7 @@ def main():
     import torch.distributed as dist
     import mipt
     from mipt import scenes
+    from mipt import distributed as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -72,12 +129,15 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- host side: scene, BVH; then upload ------------------------------------------------
-    vtx, idx, mats, mids = scenes.atrium(args.tris, seed=42)
+    vtx, idx, mats, mids, make_camera, scene_name, data_kind = load_workload(args, mipt, scenes)
     t0 = time.time()
     # binned SAH as the reference configures its builder (src/main_granite.cpp:176), then two
     # rounds of insertion-based optimisation of the finished tree (untimed, like the build)
     bvh_opts = {"bvh.builder": "sah", "mipt.optimize_passes": "2"}
+    if 2 * idx.shape[0] - 1 > (1 << 24):
+        bvh_opts["mipt.link_encoding"] = "int"
     bvh_opts.update(dict(o.split("=", 1) for o in args.bvh_option))
+    link_enc = mipt.PT_LINKS_INT_BITS if bvh_opts.get("mipt.link_encoding") == "int" else mipt.PT_LINKS_FLOAT_VALUE
     nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**bvh_opts))
     build_s = time.time() - t0
     ctx = mipt.Context(local_rank)
@@ -87,48 +147,70 @@ def main():
     for opt in args.option:
         key, _, val = opt.partition("=")
         ctx.set_option(key, int(val))
-    scene = mipt.Scene(ctx, nodes, vtx, idx, mats, mids)
+    scene = mipt.Scene(ctx, nodes, vtx, idx, mats, mids, link_encoding=link_enc)
     W, H, spp = args.width, args.height, args.spp_per_step
-    cam = scenes.atrium_camera(W / H)
+    cam = make_camera(W / H)
     film_t = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     film = mipt.Film(ctx, W, H, device_ptr=film_t.data_ptr())
     sky = (0.55, 0.65, 0.8)
-
-    from mipt import distributed as D
-
     base_flags = mipt.PT_RENDER_NEE if args.nee else 0
+    strong = args.scaling == "strong"
+
+    # ---- the communicator of the frame assembly ---------------------------------------------
+    comm, assembly = None, "none"
+    if world > 1:
+        comm, assembly = D.make_comm(ctx, rank, world, prefer_abi=args.assembly == "abi")
 
     def params(step, flags=0):
-        flags |= base_flags
-        common = dict(max_depth=args.depth, seed=42, rr_start_depth=3, background=sky, flags=flags)
-        if args.sharding == "tiles":
-            # rank r renders the tiles it owns with world*spp samples: same work per rank
-            return mipt.render_params(W, H, sample_begin=step * world * spp, sample_count=world * spp,
-                                      **D.tile_shard_kwargs(rank, world, 64), **common)
-        # rank r renders samples [(step*world + r)*spp, +spp) of every pixel
-        return mipt.render_params(W, H, sample_begin=(step * world + rank) * spp, sample_count=spp,
-                                  **common)
+        """pt_render_params of this rank for one step, or None if it has nothing to render."""
+        shard = D.step_shard_kwargs(rank, world, step, spp, args.scaling, args.sharding, 64)
+        if shard is None:
+            return None
+        return mipt.render_params(W, H, max_depth=args.depth, seed=42, rr_start_depth=3, background=sky,
+                                  flags=flags | base_flags, samples_per_pass=args.samples_per_pass, **shard)
 
     def assemble():
         if world == 1:
             return
-        if args.sharding == "tiles":
+        if comm is not None:
+            if args.sharding == "tiles":
+                comm.gather_tiles(film, 64, root=0)
+            else:
+                comm.reduce_film(film, root=0)
+            ctx.synchronize()
+        elif args.sharding == "tiles":
             sizes = [film.packed_size(64, r, world) for r in range(world)]
             D.assemble_tiles(sizes, lambda r, buf: film.pack_tiles(64, r, world, buf.data_ptr()),
-                             lambda r, buf: film.unpack_tiles(64, r, world, buf.data_ptr()), "cuda")
+                             lambda r, buf: film.unpack_tiles(64, r, world, buf.data_ptr()), "cuda",
+                             sync=ctx.synchronize)
         else:
+            ctx.synchronize()
             D.assemble_samples(film_t, dst=0)
 
+    def render_step(k, flags=0):
+        p = params(k, flags)
+        return mipt.render(ctx, scene, cam, p, film, stats=True) if p is not None else mipt.RenderStats()
+
     # ---- work per ray (untimed): the same kernels with their test counters compiled in ------
-    st = mipt.render(ctx, scene, cam, params(0, mipt.PT_RENDER_COUNT_WORK), film, stats=True)
-    rays0 = st.rays_primary + st.rays_bounce          # the counters cover the closest-hit kernel only
+    st = render_step(0, mipt.PT_RENDER_COUNT_WORK)
+    rays0 = max(st.rays_primary + st.rays_bounce, 1)  # the counters cover the closest-hit kernel only
     n_box, n_tri = st.box_tests / rays0, st.tri_tests / rays0
     bytes_per_ray = 32.0 * n_box + 48.0 * n_tri + 64.0        # reference-layout bytes per ray
     film.clear()
 
+    # ---- what this GPU can gather (untimed): dependent random 64-byte fetches, the traversal's
+    # access pattern, from tables sized to each level of the memory hierarchy -----------------
+    ceilings = {}
+    if rank == 0:
+        scene_bytes = 64 * (idx.shape[0] - 1) + 48 * idx.shape[0]
+        for name, size in (("l1_resident_16KB", 16 << 10), ("l2_resident_2MB", 2 << 20),
+                           ("scene_sized_%dMB" % max(1, scene_bytes >> 20), scene_bytes),
+                           ("hbm_resident_4GB", 4 << 30)):
+            ceilings[name] = ctx.measure_gather(size, 64, 400) / 1e9
+
     ctx.set_kernel_timing(True)
     for k in range(args.warmup):
-        mipt.render(ctx, scene, cam, params(1000 + k), film, stats=True)
+        render_step(1000 + k)
     if args.warmup:
         assemble()                # the collective's first call sets up its channels: not timed
     film.clear()
@@ -138,21 +220,23 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rays = paths = ties = launches = shadow = 0
-    extend_ms = 0.0
+    kernel_ms = {"extend": 0.0, "raygen": 0.0, "shade": 0.0, "occlude": 0.0, "accumulate": 0.0}
     for k in range(args.steps):
-        st = mipt.render(ctx, scene, cam, params(k), film, stats=True)
+        st = render_step(k)
         rays += st.rays_primary + st.rays_bounce
         shadow += st.rays_shadow
         paths += st.paths
         ties += st.tie_rays
         launches += st.extend_launches
-        extend_ms += st.extend_ms
+        for name in kernel_ms:
+            kernel_ms[name] += getattr(st, name + "_ms")
     assemble()                                                 # frame assembly over RCCL
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    extend_ms = kernel_ms["extend"]
 
     agg = torch.tensor([elapsed, float(rays + shadow), float(paths)], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -164,98 +248,190 @@ def main():
 
     if rank == 0:
         img = film_t[..., :3] / film_t[..., 3:].clamp(min=1)
-        achieved = bytes_per_ray * rays / (extend_ms * 1e-3) / 1e9
+        frame_spp = float(film_t[..., 3].mean().item())
+        ext_s = max(extend_ms, 1e-9) * 1e-3
+        records = (n_box / 2 + n_tri) * rays                   # 64-byte nodes + 48-byte triangle records
         out = {
             "metric": "Mrays/s (primary+bounce%s), Sponza 1080p depth 8" % ("+shadow" if args.nee else ""),
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
+            "vs_baseline": None,
+            "dtype": "f32", "data": data_kind,
             "msamples_per_s": total_paths / elapsed / 1e6,
-            "config": {"workload": "Sponza-class atrium stand-in (%d tris, seed 42), %dx%d, "
-                                   "Lambert+GGX, max depth %d, %d spp per step per GPU; full "
+            "config": {"workload": "%s, %dx%d, Lambert+GGX, max depth %d, %d spp per step%s; full "
                                    "wavefront path tracer (raygen, extend, shade, accumulate)"
-                                   % (args.tris, W, H, args.depth, spp),
+                                   % (scene_name, W, H, args.depth, spp,
+                                      "" if world == 1 else (" of the frame, split over the ranks" if strong
+                                                             else " per GPU")),
                        "rays_per_step_per_gpu": (rays + shadow) / args.steps,
                        "shadow_rays_per_step_per_gpu": shadow / args.steps,
                        "next_event_estimation": bool(args.nee),
-                       "samples_per_pixel_total": args.steps * spp * world,
+                       "samples_per_pixel_total": frame_spp,
                        "bvh": ", ".join("%s=%s" % kv for kv in sorted(bvh_opts.items())),
                        "bvh_build_s": round(build_s, 3),
-                       "sharding": ("sample ranges per rank, RCCL reduce of the film at the end"
+                       "sharding": "none (one GPU)" if world == 1 else
+                                   ("sample ranges per rank, film summed on rank 0 at the end"
                                     if args.sharding == "samples" else
-                                    "64x64 tiles round-robin over ranks, RCCL all-gather of packed tiles")},
+                                    "64x64 tiles round-robin over ranks, packed tiles sent to rank 0 at the end"),
+                       "assembly": assembly, "ranks_in_communicator": comm.size if comm is not None else world},
             "nodes_per_ray": n_box, "tris_per_ray": n_tri, "bytes_per_ray": bytes_per_ray,
             "tie_rays": int(ties), "mean_radiance": float(img.mean().item()),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
-                         "kernel": "k_pt_extend_persistent<false>", "launches": int(launches),
-                         "avg_launch_ms": extend_ms / max(launches, 1),
-                         "kernel_time_share": extend_ms * 1e-3 / elapsed,
-                         "note": "algorithmic reference-layout bytes; the scene's 46 MB of traversal "
-                                 "data are cache resident, so this is not HBM traffic and the "
-                                 "fraction can exceed 1",
-                         # what the kernel really does: dependent gathers of 64-byte node and
-                         # 48-byte triangle records; beside it the rate of a bare gather kernel
-                         # (tools/micro/gather_nodes.hip, every lane of 5 resident workgroups
-                         # per CU chasing random 64-byte records) measured on this GPU model
-                         "records_per_s": (n_box / 2 + n_tri) * rays / (extend_ms * 1e-3),
-                         "gather_microbenchmark_records_per_s": {"16 MB table": 133e9, "2 MB table": 212e9}},
+            "kernel_ms_per_step": {k: v / args.steps for k, v in kernel_ms.items()},
+            "kernel_time_share_of_step": sum(kernel_ms.values()) * 1e-3 / elapsed,
+        }
+        # The dominant kernel.  Its scene data (tens of MB) are cache resident, so HBM is not what
+        # bounds it: it is a dependent gather of 64-byte records through the L1 address/data path.
+        # achieved = records fetched per second; peak = the best rate at which a bare gather
+        # kernel (pt_measure_gather: same grid, same loads, no arithmetic) fetched records from a
+        # cache-resident table on this GPU a moment ago.  The algorithmic reference-layout bytes
+        # and their HBM-peak ratio are kept beside it as context, not as the fraction.
+        peak_rec = max(v for k, v in ceilings.items() if not k.startswith("hbm"))
+        out["roofline"] = {
+            "bound": "l1-gather (scene cache resident; dependent 64 B record fetches)",
+            "kernel": "k_pt_extend_persistent<false>",
+            "achieved": records / ext_s / 1e9, "peak": peak_rec, "unit": "Grecords/s",
+            "frac": records / ext_s / 1e9 / peak_rec,
+            "traffic": None,
+            "launches": int(launches), "avg_launch_ms": extend_ms / max(launches, 1),
+            "kernel_time_share": extend_ms * 1e-3 / elapsed,
+            "gather_ceilings_measured_in_this_run_grecords_s": ceilings,
+            "algorithmic_gb_per_launch": bytes_per_ray * rays / max(launches, 1) / 1e9,
+            "algorithmic_gbs": bytes_per_ray * rays / ext_s / 1e9,
+            "algorithmic_gbs_over_hbm_peak": bytes_per_ray * rays / ext_s / 1e9 / HBM_PEAK_GBS,
+            "note": "algorithmic bytes are reference-layout bytes (32 B per box test, 48 B per "
+                    "triangle test, 64 B per ray) served from caches here; their ratio to HBM peak "
+                    "is not a roofline fraction and may exceed 1",
         }
         # HBM-side bytes per launch of that kernel come from hardware counters, which a
-        # benchmark cannot read on itself: they are taken from the committed rocprofv3 --pmc
+        # benchmark cannot read on itself: they are copied from the committed rocprofv3 --pmc
         # passes over this same command (profiles/collect_traffic.sh) when the workload matches.
-        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
-        default_workload = (args.tris, W, H, args.depth, spp, args.nee) == (262144, 1920, 1080, 8, 4, False)
-        if os.path.exists(tpath) and default_workload and world == 1:
+        tpath = os.path.join(REPO, "profiles", "r02_traffic.json")
+        if os.path.exists(tpath) and world == 1:
             with open(tpath) as f:
                 tr = json.load(f)
-            out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"] / 1e9
-            out["roofline"]["traffic_unit"] = "GB per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)"
-            out["roofline"]["algorithmic_gb_per_launch"] = bytes_per_ray * rays / max(launches, 1) / 1e9
-            if "counters" in tr:
-                out["roofline"]["counters"] = tr["counters"]
-        if not args.no_cpu_baseline and world == 1:      # the host-core baseline belongs to the 1-GPU line
-            out["cpu_baseline"] = cpu_baseline(args, nodes, vtx, idx, mats, mids, sky)
+            same = tr.get("workload") == [args.tris, W, H, args.depth, spp, args.samples_per_pass,
+                                          bool(args.nee), data_kind]
+            if same:
+                gb = tr["traffic_bytes_per_launch"] / 1e9
+                out["roofline"]["traffic"] = gb
+                out["roofline"]["traffic_source"] = ("copied from profiles/r02_traffic.json (rocprofv3 --pmc "
+                                                     "passes over this command: 2 x FETCH_SIZE + WRITE_SIZE), "
+                                                     "not measured by this run")
+                out["roofline"]["hbm_frac_from_traffic"] = gb / (extend_ms / max(launches, 1) * 1e-3) / HBM_PEAK_GBS
+                if "counters" in tr:
+                    out["roofline"]["counters_copied_from_profiles"] = tr["counters"]
+        if not args.no_hbm_record and world == 1:
+            out["roofline_hbm"] = hbm_record(args, ctx, torch, mipt, scenes)
+        if link_enc != mipt.PT_LINKS_FLOAT_VALUE:
+            out["cpu_baseline_skipped"] = "the CPU restatement of the renderer reads float-valued links only"
+        elif not args.no_cpu_baseline and world == 1:    # the host-core baseline belongs to the 1-GPU line
+            out["cpu_baseline"] = cpu_baseline(args, nodes, vtx, idx, mats, mids, sky, make_camera)
             out["traversal_counts_same_rays"] = traversal_counts(scene, nodes, vtx, idx)
         print(json.dumps(out), flush=True)
     film.close()
     scene.close()
+    if comm is not None:
+        comm.close()
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, nodes, vtx, idx, mats, mids, sky):
+def hbm_record(args, ctx, torch, mipt, scenes):
+    """The regime the bytes-per-ray formula was written for: a scene far larger than the caches
+    (28 M-triangle closed surface, 3.1 GB of traversal data, tree built on the GPU) and 2^24
+    incoherent secondary rays through pt_trace_closest_device.  achieved = algorithmic bytes
+    of the launch / device time of the traversal kernel alone, against HBM peak."""
+    t0 = time.time()
+    vtx, idx, _, _ = scenes.displaced_sphere(args.hbm_tris, seed=7)
+    n = args.hbm_rays
+    rays = scenes.surface_rays(vtx, idx, n, seed=7)
+    gen_s = time.time() - t0
+    ctx.set_option("build.optimize_passes", 8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sc = mipt.Scene(ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
+    ctx.synchronize()
+    build_s = time.perf_counter() - t0
+    ctx.set_option("build.optimize_passes", 0)
+    d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
+    d_h = torch.empty_like(d_r)
+    stc = sc.trace_closest_device_counted(d_r.data_ptr(), n, d_h.data_ptr())
+    n_box, n_tri = stc.box_tests / n, stc.tri_tests / n
+    bpr = 32.0 * n_box + 48.0 * n_tri + 64.0
+    ctx.set_kernel_timing(True)
+    res = {}
+    for name, sort in (("origin_cell_order", 1), ("queue_order", 0)):
+        ctx.set_option("trace.sort_rays", sort)
+        sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr())
+        ctx.synchronize()
+        k_ms, reps = 0.0, 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr())
+            k_ms += ctx.last_trace_ms()
+        ctx.synchronize()
+        res[name] = {"kernel_ms": k_ms / reps, "call_ms": (time.perf_counter() - t0) / reps * 1e3}
+    ctx.set_option("trace.sort_rays", -1)
+    hit_frac = float((d_h.view(torch.int32)[:, 1] >= 0).float().mean().item())
+    sc.close()
+    best = res["origin_cell_order"]
+    ach = bpr * n / (best["kernel_ms"] * 1e-3) / 1e9
+    rec = {"bound": "hbm", "kernel": "k_trace_ordered_persistent<false>",
+           "workload": "Lucy-class displaced closed surface, %d tris (%.2f GB of node + triangle records), "
+                       "%d secondary rays (origins on the surface, cosine directions, seed 7), tree built "
+                       "on the GPU with 8 optimisation passes in %.2f s" %
+                       (idx.shape[0], (64.0 * (idx.shape[0] - 1) + 48.0 * idx.shape[0]) / 1e9, n, build_s),
+           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "traffic": None, "launches": 3, "avg_launch_ms": best["kernel_ms"],
+           "nodes_per_ray": n_box, "tris_per_ray": n_tri, "bytes_per_ray": bpr,
+           "algorithmic_gb_per_launch": bpr * n / 1e9,
+           "mrays_per_s_kernel": n / best["kernel_ms"] / 1e3,
+           "mrays_per_s_call_incl_sort": n / best["call_ms"] / 1e3,
+           "queue_order": {"avg_launch_ms": res["queue_order"]["kernel_ms"],
+                           "mrays_per_s": n / res["queue_order"]["kernel_ms"] / 1e3,
+                           "frac": bpr * n / (res["queue_order"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "hit_fraction": hit_frac, "tie_rays": int(stc.tie_rays), "scene_and_rays_generated_s": round(gen_s, 1)}
+    tpath = os.path.join(REPO, "profiles", "r02_traffic_hbm.json")
+    if os.path.exists(tpath) and (args.hbm_tris, n) == (28_000_000, 1 << 24):
+        with open(tpath) as f:
+            tr = json.load(f)
+        rec["traffic"] = tr["traffic_bytes_per_launch"] / 1e9
+        rec["traffic_source"] = "copied from profiles/r02_traffic_hbm.json (rocprofv3 --pmc passes), not measured by this run"
+        rec["hbm_frac_from_traffic"] = rec["traffic"] / (best["kernel_ms"] * 1e-3) / HBM_PEAK_GBS
+    return rec
+
+
+def cpu_baseline(args, nodes, vtx, idx, mats, mids, sky, make_camera):
     """The CPU restatement of the same step -- the reference's IntersectSceneClosest in
     skip-link order plus this project's shading spec -- over the product's BVH, on the host
     cores this process may use, on the same frame at reduced resolution."""
     import mipt
-    from mipt import scenes
     from oracle import oracle
     oracle.build()
     cores = len(os.sched_getaffinity(0))
     cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
     s = max(1, args.cpu_baseline_scale)
     w, h = args.width // s, args.height // s
-    cam = scenes.atrium_camera(w / h)
-    steps = 3                                   # about 10 s of work on 16 cores
-    p = mipt.render_params(w, h, sample_begin=0, sample_count=steps * args.spp_per_step,
+    cam = make_camera(w / h)
+    n_spp = 12                                  # about 10 s of work on 16 cores
+    p = mipt.render_params(w, h, sample_begin=0, sample_count=n_spp,
                            max_depth=args.depth, seed=42, rr_start_depth=3, background=sky,
                            flags=mipt.PT_RENDER_NEE if args.nee else 0)
     t0 = time.perf_counter()
     _, rays = oracle.render(nodes, vtx, idx, mats, mids, cam, p, nthreads=cores)
     dt = time.perf_counter() - t0
-    # one core, on a quarter of that sample again
+    # one core, on a quarter of the pixels and a third of the samples
     w1, h1 = max(w // 2, 8), max(h // 2, 8)
-    p1 = mipt.render_params(w1, h1, sample_begin=0, sample_count=args.spp_per_step, max_depth=args.depth,
+    p1 = mipt.render_params(w1, h1, sample_begin=0, sample_count=4, max_depth=args.depth,
                             seed=42, rr_start_depth=3, background=sky,
                             flags=mipt.PT_RENDER_NEE if args.nee else 0)
     t1 = time.perf_counter()
-    _, rays1 = oracle.render(nodes, vtx, idx, mats, mids, scenes.atrium_camera(w1 / h1), p1, nthreads=1)
+    _, rays1 = oracle.render(nodes, vtx, idx, mats, mids, make_camera(w1 / h1), p1, nthreads=1)
     dt1 = time.perf_counter() - t1
     cpu_model = "unknown"
     try:
@@ -269,9 +445,9 @@ def cpu_baseline(args, nodes, vtx, idx, mats, mids, sky):
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "cpu_model": cpu_model,
             "single_core_value": rays1 / dt1 / 1e6,
-            "single_core_sample": "one step at %dx%d: %d rays in %.1f s" % (w1, h1, rays1, dt1),
-            "sample": "%d steps of the same frame at %dx%d (1/%d of the pixels), %d spp each, depth %d: "
-                      "%d rays in %.1f s" % (steps, w, h, s * s, args.spp_per_step, args.depth, rays, dt)}
+            "single_core_sample": "4 spp at %dx%d: %d rays in %.1f s" % (w1, h1, rays1, dt1),
+            "sample": "the same frame at %dx%d (1/%d of the pixels), %d spp, depth %d: "
+                      "%d rays in %.1f s" % (w, h, s * s, n_spp, args.depth, rays, dt)}
 
 
 def traversal_counts(scene, nodes, vtx, idx, n=1 << 18):

@@ -305,6 +305,19 @@ int pt_context_set_kernel_timing(pt_context *ctx, int on) {
     return PT_OK;
 }
 
+int pt_context_last_trace_ms(pt_context *ctx, double *ms) {
+    if (!ctx || !ms) return fail(PT_ERR_INVALID, "pt_context_last_trace_ms: null argument");
+    if (!ctx->trace_timed)
+        return fail(PT_ERR_INVALID, "pt_context_last_trace_ms: no pt_trace_closest* call was made "
+                                    "with kernel timing on");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipEventSynchronize(ctx->trace_events[1]));
+    float t = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&t, ctx->trace_events[0], ctx->trace_events[1]));
+    *ms = t;
+    return PT_OK;
+}
+
 int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
     if (!ctx || !key || !value) return fail(PT_ERR_INVALID, "pt_context_set_option: null argument");
     char *end = nullptr;
@@ -637,15 +650,27 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
     const bool mt = (flags & PT_TRACE_MOLLER_TRUMBORE) != 0;
     const bool fixup = (flags & PT_TRACE_NO_TIE_FIXUP) == 0;
     HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(DeviceTraceCounters), st));
+    hipEvent_t *bracket = nullptr;
+    ctx->trace_timed = false;
+    if (ctx->kernel_timing && n) {
+        for (hipEvent_t &e : ctx->trace_events)
+            if (!e) HIP_CHECK(hipEventCreate(&e));
+        bracket = ctx->trace_events;
+        ctx->trace_timed = true;
+    }
     if (scene->dev.tlas) {
         if (mt)
             return fail(PT_ERR_UNSUPPORTED,
                         "pt_trace_closest: PT_TRACE_MOLLER_TRUMBORE is not available on two-level scenes");
+        if (bracket) HIP_CHECK(hipEventRecord(bracket[0], st));
         launch_trace_two_level(st, scene->dev, rays_dev, hits_dev, n, fixup, exact, ctx->counters,
                                count, ctx->extend_config());
+        if (bracket) HIP_CHECK(hipEventRecord(bracket[1], st));
     } else if (exact) {
+        if (bracket) HIP_CHECK(hipEventRecord(bracket[0], st));
         launch_trace_skiplink(st, scene->dev, rays_dev, hits_dev, n, mt,
                               count ? ctx->counters : nullptr);
+        if (bracket) HIP_CHECK(hipEventRecord(bracket[1], st));
     } else {
         ExtendConfig cfg = ctx->extend_config();
         // Taking the rays in origin-cell order pays once the traversal layouts no longer fit
@@ -654,7 +679,7 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
         cfg.sort_rays = ctx->trace_sort_rays >= 0 ? ctx->trace_sort_rays
                                                   : (scene_bytes > (256ull << 20) && n >= (1u << 18));
         launch_trace_ordered(st, scene->dev, rays_dev, hits_dev, n, fixup, ctx->counters, count, cfg,
-                             &ctx->sort_scratch);
+                             &ctx->sort_scratch, bracket);
     }
     HIP_CHECK(hipGetLastError());
     if (stats) {

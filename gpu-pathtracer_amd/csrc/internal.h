@@ -48,6 +48,8 @@ struct pt_context {
     mipt::DeviceBuffer render_counts;   // queue sizes per pass and bounce
     mipt::DeviceBuffer stack_spill;     // see ExtendConfig::spill (allocated with the context)
     std::vector<hipEvent_t> events;     // pool for per-kernel timing
+    hipEvent_t trace_events[2] = {nullptr, nullptr};   // around the last trace call's kernel
+    bool trace_timed = false;
 
     mipt::ExtendConfig extend_config() const {
         mipt::ExtendConfig c;
@@ -67,6 +69,10 @@ struct pt_context {
         render_counts.release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         events.clear();
+        for (hipEvent_t &e : trace_events) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
         io_rays.release();
         io_hits.release();
         render_ws.release();

@@ -88,12 +88,15 @@ constexpr int kMaxBlocksPerCu = 8;      // upper end of option "extend.blocks_pe
 void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                            uint64_t n, bool moller_trumbore, DeviceTraceCounters *counters);
 
+// bracket, if given: two events recorded on the stream right before and right after the
+// traversal kernel itself (after any sorting of the rays).
 // Closest hit by ordered two-child traversal.  Rays whose result could depend on the
 // visiting order are counted in counters->tie_count and, when fixup is set, re-resolved
 // in the fixed order inside the same kernel.
 void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                           uint64_t n, bool fixup, DeviceTraceCounters *counters,
-                          bool count_work, const ExtendConfig &cfg, DeviceBuffer *sort_scratch);
+                          bool count_work, const ExtendConfig &cfg, DeviceBuffer *sort_scratch,
+                          hipEvent_t *bracket = nullptr);
 
 // Closest hit in a two-level scene (s.tlas set).  exact: meshes in the fixed skip-link order.
 // counters must be non-null (its tie_count is always written).

@@ -275,39 +275,53 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
         HIP_CHECK(hipMemsetAsync(work, 0, sizeof(DeviceTraceCounters), st));
     }
     const ExtendConfig ecfg = ctx->extend_config();
+    // Kernel timing: one event between every two launches of the call; the span between two
+    // neighbouring events is the device time of the launch recorded between them.
     const bool timing = ctx->kernel_timing;
+    enum { kRaygen, kExtend, kShade, kOcclude, kAccumulate, kKinds };
+    std::vector<int> span_kind;
     size_t n_events = 0;
     if (timing) {
-        const size_t need = 2 * (size_t)n_pass * p.max_depth;
+        const size_t need = (size_t)n_pass * (3 * (size_t)p.max_depth + 2) + 1;
         while (ctx->events.size() < need) {
             hipEvent_t e;
             HIP_CHECK(hipEventCreate(&e));
             ctx->events.push_back(e);
         }
+        span_kind.reserve(need);
+        HIP_CHECK(hipEventRecord(ctx->events[n_events++], st));
     }
+#define PT_TIMED(kind, launch)                                              \
+    do {                                                                    \
+        launch;                                                             \
+        if (timing) {                                                       \
+            HIP_CHECK(hipEventRecord(ctx->events[n_events++], st));         \
+            span_kind.push_back(kind);                                      \
+        }                                                                   \
+    } while (0)
 
     for (uint32_t pass = 0; pass < n_pass; ++pass) {
         rl.sample0 = p.sample_begin + pass * spp_pass;
         rl.n_samples = std::min(spp_pass, p.sample_count - pass * spp_pass);
         const uint64_t paths = (uint64_t)rl.n_samples * rl.map.n_local;
         unsigned int *c = counts + (size_t)pass * row;
-        launch_pt_raygen(st, rl, ws, &c[0]);
+        PT_TIMED(kRaygen, launch_pt_raygen(st, rl, ws, &c[0]));
         int buf = 0;
         for (uint32_t b = 0; b < p.max_depth; ++b) {
-            if (timing) HIP_CHECK(hipEventRecord(ctx->events[n_events++], st));
-            launch_pt_extend(st, scene->dev, ws, buf, &c[b], paths, tie_count, work, ecfg);
-            if (timing) HIP_CHECK(hipEventRecord(ctx->events[n_events++], st));
+            PT_TIMED(kExtend, launch_pt_extend(st, scene->dev, ws, buf, &c[b], paths, tie_count, work, ecfg));
             if (depth_mode) {
-                launch_pt_shade_depth(st, ws, &c[b], paths);
+                PT_TIMED(kShade, launch_pt_shade_depth(st, ws, &c[b], paths));
             } else {
                 unsigned int *sc = &c[p.max_depth + 1 + b];
-                launch_pt_shade(st, scene->dev, rl, ws, buf, &c[b], &c[b + 1], sc, paths, b);
-                if (nee && b + 1 < p.max_depth) launch_pt_occlude(st, scene->dev, ws, sc, paths, ecfg);
+                PT_TIMED(kShade, launch_pt_shade(st, scene->dev, rl, ws, buf, &c[b], &c[b + 1], sc, paths, b));
+                if (nee && b + 1 < p.max_depth)
+                    PT_TIMED(kOcclude, launch_pt_occlude(st, scene->dev, ws, sc, paths, ecfg));
                 buf ^= 1;
             }
         }
-        launch_pt_accumulate(st, rl, ws, film->data, depth_mode);
+        PT_TIMED(kAccumulate, launch_pt_accumulate(st, rl, ws, film->data, depth_mode));
     }
+#undef PT_TIMED
     HIP_CHECK(hipGetLastError());
 
     if (stats) {
@@ -331,13 +345,17 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
         }
         stats->extend_launches = (uint64_t)n_pass * p.max_depth;
         if (timing) {
-            double ms = 0.0;
-            for (size_t k = 0; k + 1 < n_events; k += 2) {
+            double ms[kKinds] = {0, 0, 0, 0, 0};
+            for (size_t k = 0; k + 1 < n_events; ++k) {
                 float t = 0.f;
                 HIP_CHECK(hipEventElapsedTime(&t, ctx->events[k], ctx->events[k + 1]));
-                ms += t;
+                ms[span_kind[k]] += t;
             }
-            stats->extend_ms = ms;
+            stats->extend_ms = ms[kExtend];
+            stats->raygen_ms = ms[kRaygen];
+            stats->shade_ms = ms[kShade];
+            stats->occlude_ms = ms[kOcclude];
+            stats->accumulate_ms = ms[kAccumulate];
         }
     }
     return PT_OK;

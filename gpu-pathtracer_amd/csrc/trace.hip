@@ -273,10 +273,13 @@ void launch_trace_two_level(hipStream_t st, const DeviceScene &s, const pt_ray *
 
 void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                           uint64_t n, bool fixup, DeviceTraceCounters *counters,
-                          bool count_work, const ExtendConfig &cfg, DeviceBuffer *sort_scratch) {
+                          bool count_work, const ExtendConfig &cfg, DeviceBuffer *sort_scratch,
+                          hipEvent_t *bracket) {
     if (n == 0) return;
     if (s.tlas) {
+        if (bracket) (void)hipEventRecord(bracket[0], st);
         launch_trace_two_level(st, s, rays, hits, n, fixup, false, counters, count_work, cfg);
+        if (bracket) (void)hipEventRecord(bracket[1], st);
         return;
     }
     if (cfg.persistent_blocks > 0) {
@@ -304,6 +307,7 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
                                    : (const void *)k_trace_ordered_persistent<false>;
         const unsigned int grid = (unsigned int)std::min<uint64_t>(
             grid_for(n), persistent_grid(k, kBlock, cfg, &occ[count_work ? 1 : 0]));
+        if (bracket) (void)hipEventRecord(bracket[0], st);
         if (count_work)
             hipLaunchKernelGGL((k_trace_ordered_persistent<true>), dim3(grid), dim3(kBlock), 0, st,
                                s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, cfg.spill,
@@ -312,15 +316,18 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
             hipLaunchKernelGGL((k_trace_ordered_persistent<false>), dim3(grid), dim3(kBlock), 0, st,
                                s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, cfg.spill,
                                cfg.spill_entries, counters, perm);
+        if (bracket) (void)hipEventRecord(bracket[1], st);
         return;
     }
     const unsigned int grid = grid_for(n);
+    if (bracket) (void)hipEventRecord(bracket[0], st);
     if (count_work)
         hipLaunchKernelGGL((k_trace_ordered<true>), dim3(grid), dim3(kBlock), 0, st, s, rays, hits,
                            n, fixup, counters);
     else
         hipLaunchKernelGGL((k_trace_ordered<false>), dim3(grid), dim3(kBlock), 0, st, s, rays,
                            hits, n, fixup, counters);
+    if (bracket) (void)hipEventRecord(bracket[1], st);
 }
 
 void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, int32_t *occluded,

@@ -78,7 +78,9 @@ class RenderStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays_primary", C.c_uint64), ("rays_bounce", C.c_uint64),
                 ("rays_shadow", C.c_uint64), ("tie_rays", C.c_uint64),
                 ("extend_launches", C.c_uint64), ("extend_ms", C.c_double),
-                ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64)]
+                ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("raygen_ms", C.c_double), ("shade_ms", C.c_double), ("occlude_ms", C.c_double),
+                ("accumulate_ms", C.c_double)]
 
 
 class MeshDesc(C.Structure):
@@ -133,7 +135,9 @@ _PROTOS = {
     "pt_context_synchronize": (C.c_int, [_vp]),
     "pt_context_set_kernel_timing": (C.c_int, [_vp, C.c_int]),
     "pt_context_set_option": (C.c_int, [_vp, C.c_char_p, C.c_char_p]),
+    "pt_context_last_trace_ms": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "pt_context_destroy": (C.c_int, [_vp]),
+    "pt_measure_gather": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "pt_scene_create": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp,
                                   C.c_uint32, _vp, C.c_uint32, _vp, C.POINTER(_vp)]),
     "pt_scene_destroy": (C.c_int, [_vp]),
@@ -188,6 +192,15 @@ _PROTOS = {
     "pt_film_packed_size": (C.c_uint64, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "pt_film_pack_tiles": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "pt_film_unpack_tiles": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
+    "pt_comm_available": (C.c_int, []),
+    "pt_comm_unique_id": (C.c_int, [_vp]),
+    "pt_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "pt_comm_create_all": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(_vp)]),
+    "pt_comm_rank": (C.c_int, [_vp]),
+    "pt_comm_size": (C.c_int, [_vp]),
+    "pt_comm_destroy": (C.c_int, [_vp]),
+    "pt_film_reduce": (C.c_int, [_vp, _vp, C.c_int]),
+    "pt_film_gather_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_int]),
     "pt_render": (C.c_int, [_vp, _vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp,
                             C.POINTER(RenderStats)]),
     "pt_render_params_default": (None, [C.POINTER(RenderParams), C.c_uint32, C.c_uint32]),
@@ -391,6 +404,18 @@ class Context:
 
     def set_kernel_timing(self, on: bool) -> None:
         _check(lib.pt_context_set_kernel_timing(self._h, int(on)))
+
+    def last_trace_ms(self) -> float:
+        """Device time of the last trace call's traversal kernel (kernel timing must be on)."""
+        out = C.c_double()
+        _check(lib.pt_context_last_trace_ms(self._h, C.byref(out)))
+        return out.value
+
+    def measure_gather(self, table_bytes: int, record_bytes: int = 64, iterations: int = 400) -> float:
+        """``pt_measure_gather``: dependent random gathers per second from a table of that size."""
+        out = C.c_double()
+        _check(lib.pt_measure_gather(self._h, table_bytes, record_bytes, iterations, C.byref(out)))
+        return out.value
 
     def close(self) -> None:
         if self._h:
@@ -648,6 +673,53 @@ class Film:
     def close(self) -> None:
         if self._h:
             lib.pt_film_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_available() -> bool:
+    return bool(lib.pt_comm_available())
+
+
+def comm_unique_id() -> bytes:
+    """``pt_comm_unique_id``: 128 bytes to hand to every rank."""
+    buf = C.create_string_buffer(128)
+    _check(lib.pt_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """``pt_comm_create``: this rank's end of an RCCL communicator on the context's GPU."""
+
+    def __init__(self, ctx: Context, unique_id: bytes, n_ranks: int, rank: int):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        self.ctx = ctx
+        self._h = _vp()
+        _check(lib.pt_comm_create(ctx._h, unique_id, n_ranks, rank, C.byref(self._h)))
+
+    @property
+    def rank(self) -> int:
+        return lib.pt_comm_rank(self._h)
+
+    @property
+    def size(self) -> int:
+        return lib.pt_comm_size(self._h)
+
+    def reduce_film(self, film: "Film", root: int = 0) -> None:
+        _check(lib.pt_film_reduce(film._h, self._h, root))
+
+    def gather_tiles(self, film: "Film", tile_size: int = 64, root: int = 0) -> None:
+        _check(lib.pt_film_gather_tiles(film._h, self._h, tile_size, root))
+
+    def close(self) -> None:
+        if self._h:
+            lib.pt_comm_destroy(self._h)
             self._h = _vp()
 
     def __del__(self):

@@ -33,22 +33,78 @@ def sample_shard_kwargs(rank: int, world: int, spp_total: int) -> dict:
     return {"sample_begin": begin, "sample_count": base + (1 if rank < extra else 0)}
 
 
+def step_shard_kwargs(rank: int, world: int, step: int, spp: int, scaling: str = "strong",
+                      sharding: str = "samples", tile_size: int = 64):
+    """The pt_render_params fields that give rank `rank` its share of step `step`, or None if
+    the rank has nothing to render in it.  scaling "strong": a step is `spp` samples per pixel
+    of the frame, split over the ranks; "weak": `spp` samples per pixel per rank, so a step of
+    the frame is `spp * world`.  Over all ranks and steps every (pixel, sample index) is
+    rendered exactly once, whatever the world size."""
+    per_step = spp if scaling == "strong" else spp * world
+    if sharding == "tiles":
+        return dict(sample_begin=step * per_step, sample_count=per_step,
+                    **tile_shard_kwargs(rank, world, tile_size))
+    rng = sample_shard_kwargs(rank, world, per_step)
+    if rng["sample_count"] == 0:
+        return None
+    return dict(sample_begin=step * per_step + rng["sample_begin"], sample_count=rng["sample_count"])
+
+
+def make_comm(ctx, rank: int, world: int, prefer_abi: bool = True, group=None):
+    """The communicator of the frame assembly: the library's own RCCL communicator
+    (pt_comm_create; its 128-byte id travels over torch.distributed), or None when the ranks
+    do not all have it -- the caller then assembles with torch.distributed, which is RCCL as
+    well.  Returns (comm or None, description).  Collective: every rank calls it."""
+    import mipt
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0 and prefer_abi and dev == "cuda":
+        try:
+            if mipt.comm_available():
+                uid.copy_(torch.frombuffer(bytearray(mipt.comm_unique_id()), dtype=torch.uint8))
+        except mipt.MiptError:
+            uid.zero_()
+    dist.broadcast(uid, src=0, group=group)
+    raw = uid.cpu().numpy().tobytes()
+    mine = 1 if (any(raw) and dev == "cuda" and mipt.comm_available()) else 0
+    agreed = torch.tensor([mine], dtype=torch.int32, device=dev)
+    dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)
+    if int(agreed.item()) == 0:
+        return None, "torch.distributed (RCCL)"
+    return mipt.Comm(ctx, raw, world, rank), "libmipt C ABI over RCCL (pt_film_reduce / pt_film_gather_tiles)"
+
+
 def assemble_tiles(packed_sizes: list, pack: Callable[[int, torch.Tensor], None],
-                   unpack: Callable[[int, torch.Tensor], None], device, group=None) -> None:
+                   unpack: Callable[[int, torch.Tensor], None], device, group=None,
+                   sync: Callable[[], None] | None = None) -> None:
     """packed_sizes[r] = float4 slots of rank r's shard.  pack(r, buf) fills buf (n,4) with this
-    rank's tiles; unpack(r, buf) scatters rank r's tiles into the local film."""
+    rank's tiles; unpack(r, buf) scatters rank r's tiles into the local film.
+
+    pack and unpack may run on a stream torch knows nothing about (a pt_context's own): `sync`
+    must then wait for that stream (Context.synchronize).  It is called after pack, before the
+    collective reads the buffer, and after the last unpack, before the buffers go back to
+    torch's allocator."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n_max = max(packed_sizes)
     mine = torch.zeros((n_max, 4), dtype=torch.float32, device=device)
-    pack(rank, mine[: packed_sizes[rank]])
     everyone = torch.empty((world, n_max, 4), dtype=torch.float32, device=device)
-    if device is not None and torch.device(device).type == "cuda":
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    if on_gpu:
+        torch.cuda.current_stream().synchronize()      # the zero fill above, before pack writes
+    pack(rank, mine[: packed_sizes[rank]])
+    if sync is not None:
+        sync()
+    if on_gpu:
         torch.cuda.current_stream().synchronize()
     dist.all_gather_into_tensor(everyone.view(-1), mine.view(-1), group=group)
+    if on_gpu:
+        torch.cuda.current_stream().synchronize()      # the gathered slices, before unpack reads
     for r in range(world):
         if r != rank:
             unpack(r, everyone[r, : packed_sizes[r]])
+    if sync is not None:
+        sync()
 
 
 def assemble_samples(film: torch.Tensor, dst: int | None = 0, group=None) -> None:

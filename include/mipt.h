@@ -99,6 +99,10 @@ typedef struct pt_render_stats {
     double   extend_ms;         /* summed device time of the closest-hit kernels, if timing is on */
     uint64_t box_tests;         /* with PT_RENDER_COUNT_WORK: AABB slab tests ... */
     uint64_t tri_tests;         /* ... and ray/triangle tests of those kernels */
+    double   raygen_ms;         /* if timing is on: summed device time of the other kernels, */
+    double   shade_ms;          /* by kind */
+    double   occlude_ms;
+    double   accumulate_ms;
 } pt_render_stats;
 
 /* ------------------------------------------------------------------------ */
@@ -184,9 +188,14 @@ int pt_context_create(int device, pt_context **out);
 int pt_context_set_stream(pt_context *ctx, void *hip_stream);
 void *pt_context_stream(pt_context *ctx);
 int pt_context_synchronize(pt_context *ctx);
-/* When on, every closest-hit kernel launch of pt_render is bracketed by HIP events on the
- * context's stream and summed into pt_render_stats.extend_ms. */
+/* When on, every kernel launch of pt_render is bracketed by HIP events on the context's
+ * stream and its device time summed into pt_render_stats.{extend,raygen,shade,occlude,
+ * accumulate}_ms. */
 int pt_context_set_kernel_timing(pt_context *ctx, int on);
+/* With timing on: device time in milliseconds of the traversal kernel of the context's last
+ * pt_trace_closest* call (the kernel alone: not the copies of the host-pointer forms, nor the
+ * sorting of the rays).  Waits for that kernel. */
+int pt_context_last_trace_ms(pt_context *ctx, double *ms);
 /* Tuning knobs (integers as strings).  "extend.persistent" 1|0: closest-hit kernel of
  * pt_render as persistent waves that refill idle lanes (default 1) or one thread per ray;
  * "extend.refill" 1..64: idle lanes that trigger a refill (default 40);
@@ -208,6 +217,15 @@ int pt_context_set_kernel_timing(pt_context *ctx, int on);
  * optimised tree with more levels than this is given up for the plain radix tree, whose
  * depth the key length bounds (256 is what the level lists of the passes hold). */
 int pt_context_set_option(pt_context *ctx, const char *key, const char *value);
+/* Measurement aid, no counterpart in the reference: the rate (records per second) at which
+ * the context's GPU serves dependent random gathers of record_bytes (16, 32, 48 or 64) from a
+ * table of table_bytes (rounded down to a power-of-two number of records), every lane of
+ * "extend.blocks_per_cu" resident workgroups per compute unit chasing `iterations` records
+ * one after the other.  That is a BVH traversal's access pattern with the arithmetic taken
+ * out: with the table sized to a cache level it is the ceiling of a traversal whose working
+ * set lies there.  Allocates and frees the table; blocking. */
+int pt_measure_gather(pt_context *ctx, uint64_t table_bytes, uint32_t record_bytes,
+                      uint32_t iterations, double *records_per_s);
 int pt_context_destroy(pt_context *ctx);
 
 /* init_device_data, src/main_granite.cpp:180-194: uploads the three storage buffers the
@@ -399,6 +417,39 @@ int pt_film_pack_tiles(pt_film *film, uint32_t tile_size, uint32_t shard_index,
                        uint32_t shard_count, float *packed_dev);
 int pt_film_unpack_tiles(pt_film *film, uint32_t tile_size, uint32_t shard_index,
                          uint32_t shard_count, const float *packed_dev);
+
+/* ------------------------------------------------------------------------ */
+/* Multi-GPU frame assembly over RCCL.  The reference is single-device and reads its image
+ * back with readback_ssbo (src/main_granite.cpp:499-522); with one context per GPU, scene
+ * replicated and the frame sharded by pt_render_params (tiles or sample ranges), these calls
+ * bring the shards together on the context's stream before that read-back.  RCCL is loaded
+ * at run time (librccl.so.1) on first use; PT_ERR_UNSUPPORTED if it cannot be found. */
+typedef struct pt_comm pt_comm;
+#define PT_COMM_ID_BYTES 128
+int pt_comm_available(void);                         /* 1 if RCCL could be loaded */
+/* ncclGetUniqueId: call on one rank, hand the 128 bytes to all others (any transport). */
+int pt_comm_unique_id(void *id);
+/* ncclCommInitRank on the context's GPU: one process (or thread) per GPU; collective, every
+ * rank calls it with the same id and n_ranks. */
+int pt_comm_create(pt_context *ctx, const void *id, int n_ranks, int rank, pt_comm **out);
+/* ncclCommInitAll: one process driving n GPUs, one context each; out receives n handles, rank
+ * i on ctxs[i].  Collective calls below are then made for every handle, each from the thread
+ * that drives its context. */
+int pt_comm_create_all(pt_context *const *ctxs, int n, pt_comm **out);
+int pt_comm_rank(const pt_comm *comm);
+int pt_comm_size(const pt_comm *comm);
+int pt_comm_destroy(pt_comm *comm);
+/* Sample sharding (every rank rendered its own sample range of the whole frame): the films
+ * -- radiance sums and sample counts -- are added up, in place, on rank `root` (ncclReduce;
+ * other ranks' films are left as they are) or on every rank when root < 0 (ncclAllReduce).
+ * Asynchronous on the context's stream; pt_film_read orders after it. */
+int pt_film_reduce(pt_film *film, pt_comm *comm, int root);
+/* Tile sharding (rank r rendered the tiles t with t % size == r, pt_render_params.shard_*):
+ * every peer packs its tiles and sends them straight to `root` (grouped ncclSend/ncclRecv:
+ * each slice crosses only the link between its owner and the root), where they are scattered
+ * into the film; root < 0: every rank receives every slice (ncclAllGather).  The assembled
+ * frame equals a single-GPU render bit for bit.  Asynchronous on the context's stream. */
+int pt_film_gather_tiles(pt_film *film, pt_comm *comm, uint32_t tile_size, int root);
 
 /* One frame's worth of work of the "path_trace" pass callback, src/main_granite.cpp:402-451
  * (bind the scene buffers and the camera, draw): renders params->sample_count samples per

@@ -67,7 +67,13 @@ def _worker(rank, world, port, out_dir):
             ok = xy[:, 0] >= 0
             ft[xy[ok, 1], xy[ok, 0]] = buf[torch.from_numpy(ok)]
 
-        D.assemble_tiles([len(l) for l in layouts], pack, unpack, device="cpu")
+        # without GPUs the ranks must agree on the torch.distributed fallback, not hang
+        comm, how = D.make_comm(None, rank, world)
+        assert comm is None and "torch" in how
+        calls = []
+        D.assemble_tiles([len(l) for l in layouts], pack, unpack, device="cpu",
+                         sync=lambda: calls.append(1))
+        assert len(calls) == 2
         np.save(os.path.join(out_dir, f"tiles_{rank}.npy"), ft.numpy())
 
         # ---- sample ranges ------------------------------------------------------------------
@@ -118,6 +124,25 @@ def test_shard_layout_partitions_the_image():
     parts = [D.sample_shard_kwargs(r, 3, 10) for r in range(3)]
     assert [p["sample_count"] for p in parts] == [4, 3, 3]
     assert [p["sample_begin"] for p in parts] == [0, 4, 7]
+    # the benchmark's split of a frame over ranks and steps: every (tile, sample index) is
+    # rendered exactly once, whatever the world size, under strong and weak scaling alike
+    for world in (1, 2, 3, 8):
+        for scaling in ("strong", "weak"):
+            for sharding in ("samples", "tiles"):
+                spp, steps = 5, 3
+                per_step = spp if scaling == "strong" else spp * world
+                seen = np.zeros((world if sharding == "tiles" else 1, steps * per_step), dtype=np.int32)
+                for r in range(world):
+                    for k in range(steps):
+                        kw = D.step_shard_kwargs(r, world, k, spp, scaling, sharding, 64)
+                        if kw is None:
+                            assert sharding == "samples" and spp < world
+                            continue
+                        row = kw["shard_index"] if sharding == "tiles" else 0
+                        if sharding == "tiles":
+                            assert kw["shard_count"] == world and kw["tile_size"] == 64
+                        seen[row, kw["sample_begin"]:kw["sample_begin"] + kw["sample_count"]] += 1
+                assert (seen == 1).all(), (world, scaling, sharding)
     with pytest.raises(mipt.MiptError):
         mipt.shard_layout(64, 64, 12, 0, 1)
     with pytest.raises(mipt.MiptError):

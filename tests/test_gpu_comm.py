@@ -1,0 +1,66 @@
+"""The RCCL entry points of the C ABI (pt_comm_*, pt_film_reduce, pt_film_gather_tiles) on the one
+GPU a test box has: a communicator of one rank, made both ways (by unique id as one process per
+GPU does, and by pt_comm_create_all as one process driving several GPUs does).  With one rank the
+assembled frame must be the rank's own film, bit for bit; what several ranks exchange is covered
+on the CPU (tests/test_distributed_cpu.py) through the same sharding rules."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _film_with_content(mipt, scenes, ctx):
+    vtx, idx, mats, mids = scenes.cornell_box()
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+    sc = mipt.Scene(ctx, nodes, vtx, idx, mats, mids)
+    cam = mipt.look_at_camera((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), fovy_deg=39.3, aspect=1.5)
+    film = mipt.Film(ctx, 96, 64)
+    mipt.render(ctx, sc, cam, mipt.render_params(96, 64, sample_count=3, max_depth=3, seed=9), film)
+    return sc, film
+
+
+def test_one_rank_communicator_by_unique_id(mipt, scenes, gpu_ctx):
+    assert mipt.comm_available()
+    uid = mipt.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = mipt.Comm(gpu_ctx, uid, 1, 0)
+    sc, film = _film_with_content(mipt, scenes, gpu_ctx)
+    try:
+        assert (comm.rank, comm.size) == (0, 1)
+        before = film.read()
+        assert before[..., 3].min() == 3
+        comm.reduce_film(film, root=0)
+        comm.reduce_film(film, root=-1)                 # all-reduce form
+        comm.gather_tiles(film, 16, root=0)
+        comm.gather_tiles(film, 16, root=-1)
+        np.testing.assert_array_equal(film.read().view(np.uint32), before.view(np.uint32))
+        with pytest.raises(mipt.MiptError):
+            comm.reduce_film(film, root=1)              # no such rank
+    finally:
+        film.close()
+        sc.close()
+        comm.close()
+    with pytest.raises(mipt.MiptError):
+        mipt.Comm(gpu_ctx, uid, 2, 2)                   # rank outside the communicator
+
+
+def test_one_process_communicators(mipt, scenes, gpu_ctx):
+    """pt_comm_create_all: what examples/ptrender.cpp --gpus N uses."""
+    handles = (C.c_void_p * 1)(gpu_ctx._h)
+    out = (C.c_void_p * 1)()
+    assert mipt.lib.pt_comm_create_all(handles, 1, out) == mipt.PT_OK, mipt.last_error()
+    sc, film = _film_with_content(mipt, scenes, gpu_ctx)
+    try:
+        assert mipt.lib.pt_comm_size(out[0]) == 1 and mipt.lib.pt_comm_rank(out[0]) == 0
+        before = film.read()
+        assert mipt.lib.pt_film_reduce(film._h, out[0], 0) == mipt.PT_OK, mipt.last_error()
+        np.testing.assert_array_equal(film.read().view(np.uint32), before.view(np.uint32))
+    finally:
+        film.close()
+        sc.close()
+        mipt.lib.pt_comm_destroy(out[0])
+    two = (C.c_void_p * 2)(gpu_ctx._h, gpu_ctx._h)
+    out2 = (C.c_void_p * 2)()
+    assert mipt.lib.pt_comm_create_all(two, 2, out2) == mipt.PT_ERR_INVALID      # two contexts on one GPU
