@@ -56,6 +56,50 @@ void DeviceBuffer::release() {
 
 } // namespace mipt
 
+namespace mipt {
+ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bool sorted) {
+    ExtendConfig c;
+    c.device = ctx->device;
+    c.persistent_blocks = ctx->extend_persistent ? 1 : 0;
+    c.num_cus = ctx->num_cus;
+    c.blocks_per_cu = ctx->extend_blocks_per_cu > 0 ? ctx->extend_blocks_per_cu : 5;
+    c.refill = ctx->extend_refill;
+    c.leaf_lanes = ctx->extend_leaf_lanes;
+    c.sort_rays = 0;
+    c.spill = (int32_t *)ctx->stack_spill.ptr;
+    c.spill_entries = ctx->stack_spill.ptr ? kSpillEntries : 0;
+    c.max_grid = 0;
+    // The LDS of a persistent workgroup (measured on MI355X, 262 K-triangle scene in the caches
+    // and 28 M-triangle scene beyond them):
+    //  - a tree of moderate depth gets by with 16 stack entries per lane, and 224 cached nodes
+    //    (the top 7-8 levels) take a tenth off the launch;
+    //  - a deep tree (GPU-built trees over millions of triangles: 50-70 levels) needs its stack,
+    //    or its rays live in the global spill slots: 24 entries + 96 nodes;
+    //  - incoherent rays on a scene beyond the Infinity Cache run best with four workgroups per
+    //    compute unit instead of five (fewer rays in flight thrash the caches less): the LDS
+    //    that frees goes to the full stack and 128 nodes.
+    const DeviceScene &d = scene->dev;
+    const bool two_level = d.tlas != nullptr;
+    const bool shallow = !two_level && d.wide_depth <= PT_CACHE_MAX_TREE_DEPTH;
+    const uint64_t scene_bytes = 64ull * d.n_wnodes + 48ull * d.n_tri;
+    const bool beyond_caches = scene_bytes > (256ull << 20);
+    int stack = PT_LDS_STACK_ENTRIES, cache = 0;
+    if (shallow) {
+        stack = 16; cache = 224;
+    } else if (!two_level) {
+        if (beyond_caches && !sorted) {
+            stack = PT_LDS_STACK_ENTRIES; cache = 128;
+            if (ctx->extend_blocks_per_cu <= 0) c.blocks_per_cu = 4;
+        } else {
+            stack = 24; cache = 96;
+        }
+    }
+    c.stack_entries = ctx->extend_stack_entries > 0 ? ctx->extend_stack_entries : stack;
+    c.cache_nodes = ctx->extend_cache_nodes >= 0 ? ctx->extend_cache_nodes : cache;
+    return c;
+}
+} // namespace mipt
+
 #define PT_TRY try {
 #define PT_CATCH                                                                   \
     }                                                                              \
@@ -270,8 +314,8 @@ int pt_context_create(int device, pt_context **out) {
     HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(DeviceTraceCounters), ctx->stream));
     // stack slots in global memory for the few rays that outgrow the LDS stack, for every lane
     // of the largest persistent grid; without them such rays fall back to the fixed-order walk
-    if (ctx->stack_spill.reserve((size_t)ctx->num_cus * kMaxBlocksPerCu * PT_TRACE_BLOCK *
-                                 kSpillEntries * sizeof(int32_t)) != PT_OK)
+    if (ctx->stack_spill.reserve((size_t)ctx->num_cus * kMaxLanesPerCu * kSpillEntries *
+                                 sizeof(int32_t)) != PT_OK)
         (void)hipGetLastError();
     // this device's address of the static scratch array of pt_trace_closest_device_static
     const int src = static_scratch_init(device);
@@ -346,8 +390,19 @@ int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
     } else if (k == "extend.refill") {
         if (v < 1 || v > 64) return fail(PT_ERR_INVALID, "extend.refill must be in [1,64]");
         ctx->extend_refill = (int)v;
+    } else if (k == "extend.stack_entries") {
+        if (v != -1 && (v < 9 || v > PT_LDS_STACK_ENTRIES))
+            return fail(PT_ERR_INVALID, "extend.stack_entries must be -1 or in [9," +
+                                            std::to_string(PT_LDS_STACK_ENTRIES) + "]");
+        ctx->extend_stack_entries = (int)v;
+    } else if (k == "extend.cache_nodes") {
+        if (v < -1 || v > PT_LDS_NODE_CACHE_MAX)
+            return fail(PT_ERR_INVALID, "extend.cache_nodes must be in [-1," +
+                                            std::to_string(PT_LDS_NODE_CACHE_MAX) + "]");
+        ctx->extend_cache_nodes = (int)v;
     } else if (k == "extend.blocks_per_cu") {
-        if (v < 1 || v > 8) return fail(PT_ERR_INVALID, "extend.blocks_per_cu must be in [1,8]");
+        if (v != -1 && (v < 1 || v > 8))
+            return fail(PT_ERR_INVALID, "extend.blocks_per_cu must be -1 or in [1,8]");
         ctx->extend_blocks_per_cu = (int)v;
     } else {
         return fail(PT_ERR_INVALID, "unknown option '" + k + "'");
@@ -365,6 +420,29 @@ int pt_context_destroy(pt_context *ctx) {
 }
 
 /* ---------------------------------------------------------------------- */
+
+
+// The copy of the top of the tree that the persistent kernels keep in LDS (single-level scenes).
+static int attach_top_cache(pt_context *ctx, pt_scene *sc) {
+    if (sc->dev.n_wnodes < 2) return PT_OK;
+    void *buf = nullptr;
+    // nodes, then each node's index in wnodes, then the count the builder reports
+    const size_t node_bytes = 64 * (size_t)kNodeCacheMax, index_bytes = 4 * (size_t)kNodeCacheMax;
+    hipError_t e = hipMalloc(&buf, node_bytes + index_bytes + 16);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(top cache)");
+    sc->allocs.push_back(buf);
+    int32_t *index = reinterpret_cast<int32_t *>((char *)buf + node_bytes);
+    uint32_t *n_dev = reinterpret_cast<uint32_t *>((char *)buf + node_bytes + index_bytes);
+    launch_build_top_cache(ctx->stream, sc->dev.wnodes, sc->dev.n_wnodes, (float4 *)buf, index, n_dev);
+    uint32_t n = 0;
+    e = hipMemcpyAsync(&n, n_dev, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return hip_fail(e, "top cache build");
+    sc->dev.top_cache = (const float4 *)buf;
+    sc->dev.top_global = index;
+    sc->dev.n_top_cache = n;
+    return PT_OK;
+}
 
 int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
                     uint32_t link_encoding, const float *vtx, uint32_t n_vtx, const int32_t *idx,
@@ -480,6 +558,10 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     d.n_materials = (uint32_t)mats.size();
     d.link_enc = link_encoding;
     d.wide_depth = wide.max_depth;
+    if (n_tri >= 2) {
+        const int rc = attach_top_cache(ctx, sc.get());
+        if (rc != PT_OK) return rc;
+    }
     *out = sc.release();
     return PT_OK;
     PT_CATCH
@@ -608,12 +690,17 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
     d.n_materials = (uint32_t)mats.size();
     d.link_enc = link_encoding;
     d.wide_depth = br.max_depth;
+    {
+        const int rc = attach_top_cache(ctx, sc.get());
+        if (rc != PT_OK) return rc;
+    }
     *out = sc.release();
     return PT_OK;
     PT_CATCH
 }
 
 uint32_t pt_scene_node_count(const pt_scene *scene) { return scene ? scene->dev.n_nodes : 0; }
+uint32_t pt_scene_tree_depth(const pt_scene *scene) { return scene ? scene->dev.wide_depth : 0; }
 uint32_t pt_scene_link_encoding(const pt_scene *scene) { return scene ? scene->dev.link_enc : 0; }
 
 int pt_scene_read_nodes(pt_scene *scene, pt_bbox *nodes) {
@@ -664,7 +751,7 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
                         "pt_trace_closest: PT_TRACE_MOLLER_TRUMBORE is not available on two-level scenes");
         if (bracket) HIP_CHECK(hipEventRecord(bracket[0], st));
         launch_trace_two_level(st, scene->dev, rays_dev, hits_dev, n, fixup, exact, ctx->counters,
-                               count, ctx->extend_config());
+                               count, make_extend_config(ctx, scene, false));
         if (bracket) HIP_CHECK(hipEventRecord(bracket[1], st));
     } else if (exact) {
         if (bracket) HIP_CHECK(hipEventRecord(bracket[0], st));
@@ -672,12 +759,13 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
                               count ? ctx->counters : nullptr);
         if (bracket) HIP_CHECK(hipEventRecord(bracket[1], st));
     } else {
-        ExtendConfig cfg = ctx->extend_config();
         // Taking the rays in origin-cell order pays once the traversal layouts no longer fit
         // the 256 MB Infinity Cache and the call is large enough to amortise the sort.
         const uint64_t scene_bytes = 64ull * scene->dev.n_wnodes + 48ull * scene->dev.n_tri;
-        cfg.sort_rays = ctx->trace_sort_rays >= 0 ? ctx->trace_sort_rays
-                                                  : (scene_bytes > (256ull << 20) && n >= (1u << 18));
+        const bool sort = ctx->trace_sort_rays >= 0 ? ctx->trace_sort_rays != 0
+                                                    : (scene_bytes > (256ull << 20) && n >= (1u << 18));
+        ExtendConfig cfg = make_extend_config(ctx, scene, sort);
+        cfg.sort_rays = sort ? 1 : 0;
         launch_trace_ordered(st, scene->dev, rays_dev, hits_dev, n, fixup, ctx->counters, count, cfg,
                              &ctx->sort_scratch, bracket);
     }
@@ -718,7 +806,7 @@ int pt_trace_closest_device_static(pt_context *ctx, const pt_scene *scene, const
     PT_TRY
     HIP_CHECK(hipSetDevice(ctx->device));
     const int rc = launch_trace_static(ctx->stream, ctx->device, scene->dev, rays_dev, hits_dev, n,
-                                       flags, ctx->extend_config());
+                                       flags, make_extend_config(ctx, scene, false));
     if (rc != PT_OK) return rc;
     HIP_CHECK(hipGetLastError());
     return PT_OK;
@@ -772,7 +860,7 @@ int pt_trace_any_device(pt_context *ctx, const pt_scene *scene, const pt_ray *ra
     if (n > PT_TRACE_MAX_RAYS)
         return fail(PT_ERR_INVALID, "pt_trace_any: more than 2^31-64 rays in one call");
     launch_trace_any(ctx->stream, scene->dev, rays_dev, occluded_dev, n, ctx->any_exact_order != 0,
-                     ctx->extend_config());
+                     make_extend_config(ctx, scene, false));
     HIP_CHECK(hipGetLastError());
     return PT_OK;
 }
@@ -793,7 +881,7 @@ int pt_trace_any(pt_context *ctx, const pt_scene *scene, const pt_ray *rays, uin
     HIP_CHECK(hipMemcpyAsync(ctx->io_rays.ptr, rays, sizeof(pt_ray) * n, hipMemcpyHostToDevice,
                              ctx->stream));
     launch_trace_any(ctx->stream, scene->dev, (const pt_ray *)ctx->io_rays.ptr,
-                     (int32_t *)ctx->io_hits.ptr, n, ctx->any_exact_order != 0, ctx->extend_config());
+                     (int32_t *)ctx->io_hits.ptr, n, ctx->any_exact_order != 0, make_extend_config(ctx, scene, false));
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(occluded, ctx->io_hits.ptr, sizeof(int32_t) * n,
                              hipMemcpyDeviceToHost, ctx->stream));

@@ -34,7 +34,9 @@ struct pt_context {
     int extend_persistent = 1;      // option "extend.persistent"
     int extend_refill = 40;         // option "extend.refill"
     int extend_leaf_lanes = 16;     // option "extend.leaf_lanes"
-    int extend_blocks_per_cu = 5;   // option "extend.blocks_per_cu"
+    int extend_blocks_per_cu = -1;  // option "extend.blocks_per_cu" (-1: chosen per scene, 5 or 4)
+    int extend_stack_entries = -1;  // option "extend.stack_entries" (-1: chosen per scene)
+    int extend_cache_nodes = -1;    // option "extend.cache_nodes" (-1: chosen per scene)
     int any_exact_order = 0;        // option "any.exact_order"
     int trace_sort_rays = -1;       // option "trace.sort_rays": 0 off, 1 on, -1 by scene size
     int build_ploc_radius = 0;      // option "build.ploc_radius": 0 = radix tree, else clustering
@@ -50,20 +52,6 @@ struct pt_context {
     std::vector<hipEvent_t> events;     // pool for per-kernel timing
     hipEvent_t trace_events[2] = {nullptr, nullptr};   // around the last trace call's kernel
     bool trace_timed = false;
-
-    mipt::ExtendConfig extend_config() const {
-        mipt::ExtendConfig c;
-        c.persistent_blocks = extend_persistent ? 1 : 0;
-        c.num_cus = num_cus;
-        c.blocks_per_cu = extend_blocks_per_cu;
-        c.refill = extend_refill;
-        c.leaf_lanes = extend_leaf_lanes;
-        c.sort_rays = 0;
-        c.spill = (int32_t *)stack_spill.ptr;
-        c.spill_entries = stack_spill.ptr ? mipt::kSpillEntries : 0;
-        c.max_grid = 0;
-        return c;
-    }
 
     void release_all() {
         render_counts.release();
@@ -84,6 +72,14 @@ struct pt_context {
         own_stream = nullptr;
     }
 };
+
+namespace mipt {
+// How the traversal kernels of a call on `scene` are launched: the context's options, and where
+// they are left at "auto" the per-scene choice of how a persistent workgroup's LDS is split
+// between the lanes' stacks and the cached top of the tree.  sorted: the call takes its rays in
+// origin-cell order.
+ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bool sorted);
+}
 
 struct pt_bvh {
     std::vector<pt_bbox> nodes;

@@ -44,6 +44,12 @@ struct DeviceScene {
     uint32_t n_nodes, n_tri, n_wnodes, n_materials;
     uint32_t link_enc;
     uint32_t wide_depth;
+    // Single-level scenes: the first n_top_cache two-child nodes in breadth-first order from the
+    // root, as the persistent kernels copy them to LDS.  A child that lies in this array itself
+    // is named kLdsNodeBase + its position here; other children as in wnodes.
+    const float4 *top_cache;
+    const int32_t *top_global;   // index in wnodes of each node of top_cache
+    uint32_t n_top_cache;
     // Two-level scenes only (tlas != nullptr): a skip-link tree over the instances whose leaf
     // payload is an instance index (the "top-level BVH" of src/bvh/bvh_builder.h:31); the
     // arrays above then hold every mesh back to back, in object space, except stris, which
@@ -52,6 +58,22 @@ struct DeviceScene {
     const float4 *wtop;    // the same top-level tree as two-child nodes; leaf child = ~instance
     const DeviceInstance *instances;
     uint32_t n_tlas_nodes, n_instances;
+};
+
+constexpr int32_t kLdsNodeBase = 1 << 30;
+constexpr int kNodeCacheMax = PT_LDS_NODE_CACHE_MAX;
+// Fills top_cache and top_global (room for kNodeCacheMax nodes each) from wnodes and writes the
+// number of nodes to *n_out.
+void launch_build_top_cache(hipStream_t st, const float4 *wnodes, uint32_t n_wnodes, float4 *cache,
+                            int32_t *global_index, uint32_t *n_out);
+
+// What a persistent traversal kernel is told about its own loop.
+struct PersistentParams {
+    int refill, leaf_lanes;
+    int32_t *spill;
+    int spill_entries;
+    int stack_cap;      // per-lane LDS stack entries (without the bottom sentinel)
+    int cache_nodes;    // nodes of the scene's top_cache a workgroup keeps in LDS
 };
 
 // Device counters of a trace call (mirrors pt_trace_stats, device side).
@@ -64,6 +86,7 @@ struct DeviceTraceCounters {
 
 // How the closest-hit kernels are launched.
 struct ExtendConfig {
+    int device;             // HIP device the launch goes to
     int persistent_blocks;  // > 0: persistent waves; 0: one thread per ray
     int num_cus;            // compute units of the device
     int blocks_per_cu;      // persistent form: upper bound on workgroups per compute unit
@@ -74,6 +97,10 @@ struct ExtendConfig {
     // holds, spill_entries slots for each lane of the largest grid (kSpillEntries, or 0)
     int32_t *spill;
     int spill_entries;
+    // persistent form: per-lane LDS stack entries, and how many two-child nodes from the top of
+    // the tree every workgroup keeps in LDS (single-level scenes; 0: none)
+    int stack_entries;
+    int cache_nodes;
     // persistent form: upper bound on the grid in workgroups (0: none), for a spill area that
     // was sized for fewer lanes than the device could keep resident
     unsigned int max_grid;
@@ -83,6 +110,8 @@ struct ExtendConfig {
 // PT_LDS_STACK_ENTRIES + kSpillEntries pending nodes before it is left to the fixed-order walk.
 constexpr int kSpillEntries = 48;
 constexpr int kMaxBlocksPerCu = 8;      // upper end of option "extend.blocks_per_cu"
+constexpr unsigned int kLdsBudgetPerCu = 155u * 1024u;   // LDS that resident workgroups may add up to
+constexpr int kMaxLanesPerCu = 2048;    // 32 resident waves: what the spill area is sized for
 
 // Closest hit in the reference's fixed skip-link order.
 void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
@@ -119,8 +148,27 @@ void launch_rebase_children(hipStream_t st, float4 *wnodes, uint32_t n_nodes, ui
 
 // Workgroups of `block` threads a persistent kernel may launch and still have them all
 // resident: compute units x min(cap, what the occupancy query admits).
+// lds_bytes: the workgroup's dynamic LDS (persistent_lds_bytes).
 unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg,
-                             std::atomic<int> *cache);
+                             unsigned int lds_bytes);
+// LDS of one workgroup of a persistent traversal kernel (passed as dynamic shared memory): the
+// lanes' stacks with their bottom sentinels, then the cached top of the tree.
+inline unsigned int persistent_lds_bytes(const PersistentParams &pp) {
+    return (unsigned int)((pp.stack_cap + 1) * PT_TRACE_BLOCK * 4 + 64 * pp.cache_nodes);
+}
+// The loop parameters of a launch on scene s: the cache applies to single-level scenes only and
+// never holds more nodes than the scene has prepared.
+inline PersistentParams persistent_params(const ExtendConfig &cfg, const DeviceScene &s) {
+    PersistentParams pp;
+    pp.refill = cfg.refill;
+    pp.leaf_lanes = cfg.leaf_lanes;
+    pp.spill = cfg.spill;
+    pp.spill_entries = cfg.spill_entries;
+    pp.stack_cap = cfg.stack_entries;
+    pp.cache_nodes = s.tlas ? 0 : (int)(cfg.cache_nodes < (int)s.n_top_cache ? cfg.cache_nodes : s.n_top_cache);
+    if (pp.cache_nodes < 0) pp.cache_nodes = 0;
+    return pp;
+}
 
 // Occlusion query.  exact_order: walk the skip links as the reference does; otherwise the
 // two-child nodes, nearer child first (the answer is the same).

@@ -68,7 +68,7 @@ extern "C" int pt_measure_gather(pt_context *ctx, uint64_t table_bytes, uint32_t
         return fail(PT_ERR_INVALID, "pt_measure_gather: table smaller than 64 records");
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-    const unsigned int grid = (unsigned int)(ctx->num_cus * ctx->extend_blocks_per_cu);
+    const unsigned int grid = (unsigned int)(ctx->num_cus * (ctx->extend_blocks_per_cu > 0 ? ctx->extend_blocks_per_cu : 5));
     uint4 *table = nullptr;
     uint32_t *out = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -41,6 +41,15 @@ constexpr int kTraceBlock = PT_TRACE_BLOCK;
 constexpr int kTraceStack = PT_LDS_STACK_ENTRIES;
 constexpr int32_t kSentinel = INT_MIN;
 
+// The dynamic LDS of a persistent kernel's workgroup (kPersistentLdsBytes at launch).
+extern __shared__ __align__(16) unsigned char g_persistent_lds[];
+__device__ __forceinline__ int32_t *persistent_stack() {      // this lane's column
+    return reinterpret_cast<int32_t *>(g_persistent_lds) + threadIdx.x;
+}
+__device__ __forceinline__ float4 *persistent_cache(int stack_cap) {   // behind the stacks
+    return reinterpret_cast<float4 *>(g_persistent_lds + (size_t)(stack_cap + 1) * kTraceBlock * 4);
+}
+
 __device__ __forceinline__ void store_hit(pt_hit *hits, uint64_t i, int32_t shapeid, int32_t primid,
                                           float b0, float b1, float b2, float t) {
     int4 *p = reinterpret_cast<int4 *>(hits + i);
@@ -341,10 +350,12 @@ __device__ __forceinline__ void any_begin(OrderedState &st, const float4 ro, con
 // only divergent regions are the stack accesses and the work inside the triangle test.
 // ANY: occlusion query -- the triangle step is the Moller-Trumbore test of
 // shaders/RadeonRays/bvh.glslh:289-310 and the first hit ends the ray.
-template <bool COUNT, bool ANY = false>
+template <bool COUNT, bool ANY = false, bool CACHE = false>
 __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedState &st,
                                                 int32_t *stack, int min_active, int leaf_lanes,
-                                                unsigned long long &nb, unsigned long long &nt) {
+                                                unsigned long long &nb, unsigned long long &nt,
+                                                int stack_cap = kTraceStack,
+                                                const float4 *cache = nullptr) {
     for (;;) {
         // Node steps run in a loop of their own: only the position and the stack pointer
         // change in it, so the rest of the lane's state stays put in its registers.
@@ -360,9 +371,17 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
         int mode = vote(at_node, at_leaf);
         while (mode == 0) {
             if (at_node) {
-                const float4 *np = wide_node(s, st.cur);
-                const float4 a = np[0], b = np[1], c = np[2];
-                const int4 ch = reinterpret_cast<const int4 *>(np)[3];
+                float4 a, b, c;
+                int4 ch;
+                if (CACHE && st.cur >= kLdsNodeBase) {      // a node of the top of the tree, in LDS
+                    const float4 *np = cache + ((st.cur - kLdsNodeBase) << 2);
+                    a = np[0]; b = np[1]; c = np[2];
+                    ch = reinterpret_cast<const int4 *>(np)[3];
+                } else {
+                    const float4 *np = wide_node(s, st.cur);
+                    a = np[0]; b = np[1]; c = np[2];
+                    ch = reinterpret_cast<const int4 *>(np)[3];
+                }
 #ifdef PT_WAVE_ITERS
                 if (COUNT && (__ffsll(__ballot(1)) - 1) == (int)(threadIdx.x & 63)) nb += 128;
 #else
@@ -376,7 +395,7 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                 // No room for the farther child: the lane stops here with the node itself on top
                 // of its stack (the last slot is kept for that), and whoever drives the loop
                 // makes room and repeats the step (stack_service) or gives the ray up.
-                const bool full = both & (st.sp >= kTraceStack);
+                const bool full = both & (st.sp >= stack_cap);
                 int32_t next = take_b ? ch.y : ch.x;
                 const int32_t far_c = take_b ? ch.x : ch.y;
                 if (both) stack[st.sp * kTraceBlock] = full ? st.cur : far_c;
@@ -746,14 +765,36 @@ struct HitSink {
 // drains.  ANY = false: closest hits, sink(ray, shapeid, primid, b0, b1, b2, t).
 // ANY = true: occlusion queries, sink(ray, occluded).  perm, if not null, is the order in
 // which to take the rays (queue position -> ray index); sinks always get the ray index.
-template <bool COUNT, bool ANY, class Sink>
+template <bool COUNT, bool ANY, bool CACHE, class Sink>
 __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const pt_ray *rays,
-                                                    uint32_t n, bool fixup, int refill,
-                                                    int leaf_lanes, int32_t *stack,
-                                                    const StackSpill spill,
+                                                    uint32_t n, bool fixup, const PersistentParams pp,
                                                     unsigned int *tie_count,
                                                     DeviceTraceCounters *work, Sink sink,
                                                     const uint32_t *perm = nullptr) {
+    const int refill = pp.refill, leaf_lanes = pp.leaf_lanes, stack_cap = pp.stack_cap;
+    int32_t *const stack = persistent_stack();
+    const StackSpill spill = lane_spill(pp.spill, pp.spill_entries);
+    // The top of the tree goes to LDS once per workgroup, and rays then start at its first node.
+    // The scene's array names a child inside it kLdsNodeBase + position; a workgroup that keeps
+    // fewer nodes than the array holds gives the children beyond its share their global names.
+    float4 *const cache = CACHE ? persistent_cache(stack_cap) : nullptr;
+    int32_t root = 0;
+    if (CACHE) {
+        const uint32_t n_cached = min((uint32_t)pp.cache_nodes, s.n_top_cache);
+        for (uint32_t i = threadIdx.x; i < 4u * n_cached; i += kTraceBlock) {
+            float4 v = s.top_cache[i];
+            if ((i & 3u) == 3u) {
+                int32_t c0 = __float_as_int(v.x), c1 = __float_as_int(v.y);
+                if (c0 >= kLdsNodeBase + (int32_t)n_cached) c0 = s.top_global[c0 - kLdsNodeBase];
+                if (c1 >= kLdsNodeBase + (int32_t)n_cached) c1 = s.top_global[c1 - kLdsNodeBase];
+                v.x = __int_as_float(c0);
+                v.y = __int_as_float(c1);
+            }
+            cache[i] = v;
+        }
+        __syncthreads();
+        if (n_cached) root = kLdsNodeBase;
+    }
     const uint32_t lane = threadIdx.x & 63u;
     // readfirstlane: the wave index is the same in all 64 lanes, which the compiler cannot see
     // from threadIdx; with it the stream bookkeeping and the loop control stay scalar
@@ -869,8 +910,8 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                     const uint32_t ri = perm ? perm[idx] : idx;
                     const float4 ro = reinterpret_cast<const float4 *>(rays + ri)[0];
                     const float4 rd = reinterpret_cast<const float4 *>(rays + ri)[1];
-                    if constexpr (ANY) any_begin(st, ro, rd, stack, any_exact);
-                    else ordered_begin(st, ro, rd, stack);
+                    if constexpr (ANY) any_begin(st, ro, rd, stack, any_exact, root);
+                    else ordered_begin(st, ro, rd, stack, root);
                     my_ray = ri;
                     spilled = 0;
                 }
@@ -881,7 +922,8 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
             if (pos >= stream_len) break;
             continue;                                           // tail positions past the queue end
         }
-        ordered_advance<COUNT, ANY>(s, st, stack, pos < stream_len ? 64 - refill : 0, leaf_lanes, nb, nt);
+        ordered_advance<COUNT, ANY, CACHE>(s, st, stack, pos < stream_len ? 64 - refill : 0, leaf_lanes,
+                                           nb, nt, stack_cap, cache);
     }
     if constexpr (!ANY) walk_parked();
     if (!ANY && n_ties) atomicAdd(tie_count, n_ties);
@@ -914,9 +956,11 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
 // stream is finite: the grid drains.
 template <bool COUNT, bool ANY, class Sink>
 __device__ __forceinline__ void persistent_traverse_two_level(
-    const DeviceScene &s, const pt_ray *rays, uint32_t n, bool fixup, int refill, int leaf_lanes,
-    int32_t *stack, const StackSpill spill, unsigned int *tie_count, DeviceTraceCounters *work,
-    Sink sink) {
+    const DeviceScene &s, const pt_ray *rays, uint32_t n, bool fixup, const PersistentParams pp,
+    unsigned int *tie_count, DeviceTraceCounters *work, Sink sink) {
+    const int refill = pp.refill, leaf_lanes = pp.leaf_lanes, stack_cap = pp.stack_cap;
+    int32_t *const stack = persistent_stack();
+    const StackSpill spill = lane_spill(pp.spill, pp.spill_entries);
     const uint32_t lane = threadIdx.x & 63u;
     // readfirstlane: the wave index is the same in all 64 lanes, which the compiler cannot see
     // from threadIdx; with it the stream bookkeeping and the loop control stay scalar
@@ -928,7 +972,7 @@ __device__ __forceinline__ void persistent_traverse_two_level(
     const uint32_t stream_len = owned << 6;
     uint32_t pos = 0;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
-    constexpr int kTopStack = kTraceStack / 2;   // entries the top-level walk may hold
+    const int kTopStack = stack_cap / 2;         // entries the top-level walk may hold
     uint32_t my_ray = kNone;
     OrderedState st;
     st.cur = kSentinel;
@@ -1090,7 +1134,7 @@ __device__ __forceinline__ void persistent_traverse_two_level(
             continue;                                           // lanes waiting for service only
         }
         const int batch = min(refill, max(1, active >> 1));
-        ordered_advance<COUNT, ANY>(s, st, stack, active - batch, leaf_lanes, nb, nt);
+        ordered_advance<COUNT, ANY>(s, st, stack, active - batch, leaf_lanes, nb, nt, stack_cap);
     }
     if (!ANY && n_ties) atomicAdd(tie_count, n_ties);
     if (COUNT) {
@@ -1103,16 +1147,14 @@ __device__ __forceinline__ void persistent_traverse_two_level(
     }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool CACHE>
 __device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, const pt_ray *rays,
                                                         pt_hit *hits, uint32_t n, bool fixup,
-                                                        int refill, int leaf_lanes, int32_t *stack,
-                                                        const StackSpill spill,
+                                                        const PersistentParams pp,
                                                         unsigned int *tie_count,
                                                         DeviceTraceCounters *work,
                                                         const uint32_t *perm = nullptr) {
-    persistent_traverse<COUNT, false>(s, rays, n, fixup, refill, leaf_lanes, stack, spill, tie_count,
-                                      work, HitSink{hits}, perm);
+    persistent_traverse<COUNT, false, CACHE>(s, rays, n, fixup, pp, tie_count, work, HitSink{hits}, perm);
 }
 
 // Compacting append to a queue: every lane with `keep` gets a distinct slot.  One atomic

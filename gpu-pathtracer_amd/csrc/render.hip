@@ -127,13 +127,8 @@ __global__ __launch_bounds__(kBlock) void k_pt_extend_two_level(DeviceScene s, c
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_two_level_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, const unsigned int *count,
-    unsigned int *tie_count, DeviceTraceCounters *work, int refill, int leaf_lanes,
-    int32_t *spill, int spill_entries) {
-    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
-    persistent_traverse_two_level<COUNT, false>(s, rays, *count, true, refill, leaf_lanes,
-                                                s_stack + threadIdx.x,
-                                                lane_spill(spill, spill_entries), tie_count, work,
-                                                HitSink{hits});
+    unsigned int *tie_count, DeviceTraceCounters *work, PersistentParams pp) {
+    persistent_traverse_two_level<COUNT, false>(s, rays, *count, true, pp, tie_count, work, HitSink{hits});
 }
 
 // extend, persistent form: the grid is sized to the machine, not to the queue.  Queue
@@ -141,17 +136,11 @@ __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_two_l
 // static, so no work-distribution atomics), and a wave tops its idle lanes up from its own
 // stream whenever `refill` or more of them have finished, instead of idling them until its
 // slowest ray ends.
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_persistent(DeviceScene s, const pt_ray *rays,
-                                                                pt_hit *hits,
-                                                                const unsigned int *count,
-                                                                unsigned int *tie_count,
-                                                                DeviceTraceCounters *work,
-                                                                int refill, int leaf_lanes,
-                                                                int32_t *spill, int spill_entries) {
-    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];   // + the bottom sentinel
-    persistent_closest_hits<COUNT>(s, rays, hits, *count, true, refill, leaf_lanes, s_stack + threadIdx.x,
-                                   lane_spill(spill, spill_entries), tie_count, work);
+template <bool COUNT, bool CACHE>
+__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_persistent(
+    DeviceScene s, const pt_ray *rays, pt_hit *hits, const unsigned int *count,
+    unsigned int *tie_count, DeviceTraceCounters *work, PersistentParams pp) {
+    persistent_closest_hits<COUNT, CACHE>(s, rays, hits, *count, true, pp, tie_count, work);
 }
 
 // shade: one path vertex per queued hit; survivors are appended to the next queue.
@@ -286,24 +275,17 @@ __global__ __launch_bounds__(kBlock) void k_pt_occlude_two_level(DeviceScene s, 
 }
 
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_two_level_persistent(
-    DeviceScene s, RenderWorkspace ws, const unsigned int *count, int refill, int leaf_lanes,
-    int32_t *spill, int spill_entries) {
-    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
-    persistent_traverse_two_level<false, true>(s, ws.shadow_rays, *count, true, refill, leaf_lanes,
-                                               s_stack + threadIdx.x,
-                                               lane_spill(spill, spill_entries), nullptr, nullptr,
+    DeviceScene s, RenderWorkspace ws, const unsigned int *count, PersistentParams pp) {
+    persistent_traverse_two_level<false, true>(s, ws.shadow_rays, *count, true, pp, nullptr, nullptr,
                                                ShadowSink{ws.shadow_carry, ws.radiance});
 }
 
 // Persistent waves with lane refill and step voting, as the closest-hit kernel.
+template <bool CACHE>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_persistent(
-    DeviceScene s, RenderWorkspace ws, const unsigned int *count, int refill, int leaf_lanes,
-    int32_t *spill, int spill_entries) {
-    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
-    persistent_traverse<false, true>(s, ws.shadow_rays, *count, true, refill, leaf_lanes,
-                                     s_stack + threadIdx.x, lane_spill(spill, spill_entries),
-                                     nullptr, nullptr,
-                                     ShadowSink{ws.shadow_carry, ws.radiance});
+    DeviceScene s, RenderWorkspace ws, const unsigned int *count, PersistentParams pp) {
+    persistent_traverse<false, true, CACHE>(s, ws.shadow_rays, *count, true, pp, nullptr, nullptr,
+                                            ShadowSink{ws.shadow_carry, ws.radiance});
 }
 
 // PT_RENDER_DEPTH_GREY: the reference's per-pixel output (shaders/depth.frag:90-107).
@@ -370,20 +352,19 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
                       const unsigned int *count, uint64_t max_rays, unsigned int *tie_count,
                       DeviceTraceCounters *work, const ExtendConfig &cfg) {
     if (!max_rays) return;
+    const PersistentParams pp = persistent_params(cfg, s);
+    const unsigned int lds = persistent_lds_bytes(pp);
     if (s.tlas && cfg.persistent_blocks > 0) {
-        static std::atomic<int> occ2[2];
         const void *k = work ? (const void *)k_pt_extend_two_level_persistent<true>
                              : (const void *)k_pt_extend_two_level_persistent<false>;
-        const unsigned int grid = (unsigned int)std::min<uint64_t>(
-            blocks(max_rays, kBlock), persistent_grid(k, kBlock, cfg, &occ2[work ? 1 : 0]));
+        const unsigned int grid = (unsigned int)std::min<uint64_t>(blocks(max_rays, kBlock),
+                                                                   persistent_grid(k, kBlock, cfg, lds));
         if (work)
-            hipLaunchKernelGGL(k_pt_extend_two_level_persistent<true>, dim3(grid), dim3(kBlock), 0, st,
-                               s, ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes,
-                               cfg.spill, cfg.spill_entries);
+            hipLaunchKernelGGL(k_pt_extend_two_level_persistent<true>, dim3(grid), dim3(kBlock), lds, st,
+                               s, ws.rays[buf], ws.hits, count, tie_count, work, pp);
         else
-            hipLaunchKernelGGL(k_pt_extend_two_level_persistent<false>, dim3(grid), dim3(kBlock), 0, st,
-                               s, ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes,
-                               cfg.spill, cfg.spill_entries);
+            hipLaunchKernelGGL(k_pt_extend_two_level_persistent<false>, dim3(grid), dim3(kBlock), lds, st,
+                               s, ws.rays[buf], ws.hits, count, tie_count, work, pp);
         return;
     }
     if (s.tlas) {
@@ -396,19 +377,22 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
         return;
     }
     if (cfg.persistent_blocks > 0) {
-        static std::atomic<int> occ[2];
-        const void *k = work ? (const void *)k_pt_extend_persistent<true>
-                             : (const void *)k_pt_extend_persistent<false>;
-        const unsigned int grid = (unsigned int)std::min<uint64_t>(
-            blocks(max_rays, kBlock), persistent_grid(k, kBlock, cfg, &occ[work ? 1 : 0]));
-        if (work)
-            hipLaunchKernelGGL(k_pt_extend_persistent<true>, dim3(grid), dim3(kBlock), 0, st, s,
-                               ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes,
-                               cfg.spill, cfg.spill_entries);
-        else
-            hipLaunchKernelGGL(k_pt_extend_persistent<false>, dim3(grid), dim3(kBlock), 0, st, s,
-                               ws.rays[buf], ws.hits, count, tie_count, work, cfg.refill, cfg.leaf_lanes,
-                               cfg.spill, cfg.spill_entries);
+        const bool cached = pp.cache_nodes > 0;
+        const void *k = work ? (cached ? (const void *)k_pt_extend_persistent<true, true>
+                                       : (const void *)k_pt_extend_persistent<true, false>)
+                             : (cached ? (const void *)k_pt_extend_persistent<false, true>
+                                       : (const void *)k_pt_extend_persistent<false, false>);
+        const unsigned int grid = (unsigned int)std::min<uint64_t>(blocks(max_rays, kBlock),
+                                                                   persistent_grid(k, kBlock, cfg, lds));
+#define PT_LAUNCH(C, L)                                                                               \
+    hipLaunchKernelGGL((k_pt_extend_persistent<C, L>), dim3(grid), dim3(kBlock), lds, st, s, ws.rays[buf], \
+                       ws.hits, count, tie_count, work, pp)
+        if (work) {
+            if (cached) PT_LAUNCH(true, true); else PT_LAUNCH(true, false);
+        } else {
+            if (cached) PT_LAUNCH(false, true); else PT_LAUNCH(false, false);
+        }
+#undef PT_LAUNCH
         return;
     }
     if (work)
@@ -432,13 +416,14 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
                        const unsigned int *shadow_count, uint64_t max_rays,
                        const ExtendConfig &cfg) {
     if (!max_rays) return;
+    const PersistentParams pp = persistent_params(cfg, s);
+    const unsigned int lds = persistent_lds_bytes(pp);
     if (s.tlas && cfg.persistent_blocks > 0) {
-        static std::atomic<int> occ2{0};
         const unsigned int grid = (unsigned int)std::min<uint64_t>(
             blocks(max_rays, kBlock),
-            persistent_grid((const void *)k_pt_occlude_two_level_persistent, kBlock, cfg, &occ2));
-        hipLaunchKernelGGL(k_pt_occlude_two_level_persistent, dim3(grid), dim3(kBlock), 0, st, s, ws,
-                           shadow_count, cfg.refill, cfg.leaf_lanes, cfg.spill, cfg.spill_entries);
+            persistent_grid((const void *)k_pt_occlude_two_level_persistent, kBlock, cfg, lds));
+        hipLaunchKernelGGL(k_pt_occlude_two_level_persistent, dim3(grid), dim3(kBlock), lds, st, s, ws,
+                           shadow_count, pp);
         return;
     }
     if (s.tlas) {
@@ -446,13 +431,20 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
                            st, s, ws, shadow_count);
         return;
     }
-    if (cfg.persistent_blocks > 0) {
-        static std::atomic<int> occ{0};
-        const unsigned int grid = (unsigned int)std::min<uint64_t>(
-            blocks(max_rays, kBlock),
-            persistent_grid((const void *)k_pt_occlude_persistent, kBlock, cfg, &occ));
-        hipLaunchKernelGGL(k_pt_occlude_persistent, dim3(grid), dim3(kBlock), 0, st, s, ws,
-                           shadow_count, cfg.refill, cfg.leaf_lanes, cfg.spill, cfg.spill_entries);
+    if (cfg.persistent_blocks > 0 && s.n_tri >= 2) {
+        if (pp.cache_nodes > 0) {
+            const unsigned int grid = (unsigned int)std::min<uint64_t>(
+                blocks(max_rays, kBlock),
+                persistent_grid((const void *)k_pt_occlude_persistent<true>, kBlock, cfg, lds));
+            hipLaunchKernelGGL(k_pt_occlude_persistent<true>, dim3(grid), dim3(kBlock), lds, st, s, ws,
+                               shadow_count, pp);
+        } else {
+            const unsigned int grid = (unsigned int)std::min<uint64_t>(
+                blocks(max_rays, kBlock),
+                persistent_grid((const void *)k_pt_occlude_persistent<false>, kBlock, cfg, lds));
+            hipLaunchKernelGGL(k_pt_occlude_persistent<false>, dim3(grid), dim3(kBlock), lds, st, s, ws,
+                               shadow_count, pp);
+        }
         return;
     }
     hipLaunchKernelGGL(k_pt_occlude, dim3(blocks(max_rays, kBlock)), dim3(kBlock), 0, st, s, ws,

@@ -274,7 +274,7 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
         work = ctx->counters;
         HIP_CHECK(hipMemsetAsync(work, 0, sizeof(DeviceTraceCounters), st));
     }
-    const ExtendConfig ecfg = ctx->extend_config();
+    const ExtendConfig ecfg = make_extend_config(ctx, scene, false);
     // Kernel timing: one event between every two launches of the call; the span between two
     // neighbouring events is the device time of the launch recorded between them.
     const bool timing = ctx->kernel_timing;

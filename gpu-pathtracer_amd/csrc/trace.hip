@@ -7,7 +7,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <set>
 #include <string>
+#include <utility>
 
 namespace mipt {
 
@@ -67,18 +71,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_ordered(DeviceScene s, const p
     }
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_ordered_persistent(DeviceScene s,
-                                                                    const pt_ray *rays,
-                                                                    pt_hit *hits, uint32_t n,
-                                                                    bool fixup, int refill, int leaf_lanes,
-                                                                    int32_t *spill, int spill_entries,
-                                                                    DeviceTraceCounters *counters,
-                                                                    const uint32_t *perm) {
-    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];   // + the bottom sentinel
-    persistent_closest_hits<COUNT>(s, rays, hits, n, fixup, refill, leaf_lanes, s_stack + threadIdx.x,
-                                   lane_spill(spill, spill_entries), &counters->tie_count, counters,
-                                   perm);
+template <bool COUNT, bool CACHE>
+__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_ordered_persistent(
+    DeviceScene s, const pt_ray *rays, pt_hit *hits, uint32_t n, bool fixup, PersistentParams pp,
+    DeviceTraceCounters *counters, const uint32_t *perm) {
+    persistent_closest_hits<COUNT, CACHE>(s, rays, hits, n, fixup, pp, &counters->tie_count, counters, perm);
 }
 
 // IntersectSceneAny, shaders/RadeonRays/bvh.glslh:378-414 (leaf test :350-375, :289-310).
@@ -102,13 +99,10 @@ struct OccludedSink {
         out[ray] = occluded ? 1 : 0;
     }
 };
+template <bool CACHE>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_persistent(
-    DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, int refill, int leaf_lanes,
-    int32_t *spill, int spill_entries) {
-    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
-    persistent_traverse<false, true>(s, rays, n, true, refill, leaf_lanes, s_stack + threadIdx.x,
-                                     lane_spill(spill, spill_entries), nullptr, nullptr,
-                                     OccludedSink{occluded});
+    DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, PersistentParams pp) {
+    persistent_traverse<false, true, CACHE>(s, rays, n, true, pp, nullptr, nullptr, OccludedSink{occluded});
 }
 
 // Two-level scenes: one thread per ray (see closest_hit_two_level).
@@ -155,21 +149,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_two_level(DeviceScene s, c
 // Two-level scenes by persistent waves (see persistent_traverse_two_level).
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_two_level_persistent(
-    DeviceScene s, const pt_ray *rays, pt_hit *hits, uint32_t n, bool fixup, int refill,
-    int leaf_lanes, int32_t *spill, int spill_entries, DeviceTraceCounters *counters) {
-    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
-    persistent_traverse_two_level<COUNT, false>(s, rays, n, fixup, refill, leaf_lanes,
-                                                s_stack + threadIdx.x,
-                                                lane_spill(spill, spill_entries),
-                                                &counters->tie_count, counters, HitSink{hits});
+    DeviceScene s, const pt_ray *rays, pt_hit *hits, uint32_t n, bool fixup, PersistentParams pp,
+    DeviceTraceCounters *counters) {
+    persistent_traverse_two_level<COUNT, false>(s, rays, n, fixup, pp, &counters->tie_count, counters,
+                                                HitSink{hits});
 }
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_two_level_persistent(
-    DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, int refill, int leaf_lanes,
-    int32_t *spill, int spill_entries) {
-    __shared__ int32_t s_stack[(kTraceStack + 1) * kBlock];
-    persistent_traverse_two_level<false, true>(s, rays, n, true, refill, leaf_lanes,
-                                               s_stack + threadIdx.x,
-                                               lane_spill(spill, spill_entries), nullptr, nullptr,
+    DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, PersistentParams pp) {
+    persistent_traverse_two_level<false, true>(s, rays, n, true, pp, nullptr, nullptr,
                                                OccludedSink{occluded});
 }
 
@@ -202,20 +189,71 @@ __global__ __launch_bounds__(kBlock) void k_ray_keys(DeviceScene s, const pt_ray
     vals[i] = i;
 }
 
+// Breadth-first from the root: the node taken from the queue at position i becomes cache node i,
+// and a child that is itself queued (while there is room) is renamed kLdsNodeBase + its queue
+// position.  The queue is kept: it names each cache node's place in wnodes.  One thread: a few
+// hundred dependent fetches, once per scene.
+__global__ void k_build_top_cache(const float4 *wnodes, uint32_t n_wnodes, float4 *cache,
+                                  int32_t *queue, uint32_t *n_out, int capacity) {
+    if (blockIdx.x || threadIdx.x) return;
+    int count = 0;
+    if (n_wnodes > 1 && capacity > 0) {
+        queue[0] = 0;
+        count = 1;
+        for (int i = 0; i < count; ++i) {
+            const float4 *np = wnodes + 4 * (size_t)queue[i];
+            int4 ch = reinterpret_cast<const int4 *>(np)[3];
+            int32_t c[2] = {ch.x, ch.y};
+            for (int k = 0; k < 2; ++k)
+                if (c[k] >= 0 && count < capacity) {
+                    queue[count] = c[k];
+                    c[k] = kLdsNodeBase + count;
+                    ++count;
+                }
+            cache[4 * i + 0] = np[0];
+            cache[4 * i + 1] = np[1];
+            cache[4 * i + 2] = np[2];
+            reinterpret_cast<int4 *>(cache)[4 * i + 3] = make_int4(c[0], c[1], ch.z, ch.w);
+        }
+    }
+    *n_out = (uint32_t)count;
+}
+
 inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kBlock - 1) / kBlock); }
 
 } // namespace
 
+void launch_build_top_cache(hipStream_t st, const float4 *wnodes, uint32_t n_wnodes, float4 *cache,
+                            int32_t *global_index, uint32_t *n_out) {
+    hipLaunchKernelGGL(k_build_top_cache, dim3(1), dim3(1), 0, st, wnodes, n_wnodes, cache,
+                       global_index, n_out, (int)kNodeCacheMax);
+}
+
 unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg,
-                             std::atomic<int> *cache) {
-    // Never launch more persistent workgroups than can be resident at once: the surplus
-    // would only start after the first ones have finished their whole streams.
-    int per_cu = cache->load(std::memory_order_relaxed);
-    if (per_cu == 0) {               // contexts on several GPUs may get here at once: same answer
-        int nb = 0;
-        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0);
-        per_cu = (e == hipSuccess && nb > 0) ? nb : 4;
-        cache->store(per_cu, std::memory_order_relaxed);
+                             unsigned int lds_bytes) {
+    // Never launch more persistent workgroups than can be resident at once: the surplus would
+    // only start after the first ones have finished their whole streams.  The answer depends
+    // on the kernel and on its LDS size, not on the GPU (one model per process).
+    static std::mutex mu;
+    static std::map<std::pair<const void *, unsigned int>, int> resident;
+    static std::set<std::pair<const void *, int>> granted;
+    int per_cu;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        // more than 64 KB of LDS per workgroup must be granted per kernel and device
+        if (lds_bytes > 64u * 1024u && granted.insert({kernel, cfg.device}).second)
+            (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int &slot = resident[{kernel, lds_bytes}];
+        if (slot == 0) {
+            int nb = 0;
+            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, lds_bytes);
+            slot = (e == hipSuccess && nb > 0) ? nb : 1;
+            // The query admits workgroups whose LDS adds up to the full 160 KB of a compute unit;
+            // in practice the last one then does not become resident and runs as a second round
+            // (measured: 5 x 32 KB and 3 x 53 KB take 1.4-2x as long as 5 x 31 KB).
+            if (lds_bytes) slot = std::max(1, std::min(slot, (int)(kLdsBudgetPerCu / lds_bytes)));
+        }
+        per_cu = slot;
     }
     const unsigned int grid = (unsigned int)(cfg.num_cus * std::min(per_cu, cfg.blocks_per_cu));
     return cfg.max_grid ? std::min(grid, cfg.max_grid) : grid;
@@ -248,19 +286,17 @@ void launch_trace_two_level(hipStream_t st, const DeviceScene &s, const pt_ray *
                             bool count_work, const ExtendConfig &cfg) {
     if (n == 0) return;
     if (!exact && cfg.persistent_blocks > 0) {
-        static std::atomic<int> occ[2];
+        const PersistentParams pp = persistent_params(cfg, s);
+        const unsigned int lds = persistent_lds_bytes(pp);
         const void *k = count_work ? (const void *)k_trace_two_level_persistent<true>
                                    : (const void *)k_trace_two_level_persistent<false>;
-        const unsigned int grid = (unsigned int)std::min<uint64_t>(
-            grid_for(n), persistent_grid(k, kBlock, cfg, &occ[count_work ? 1 : 0]));
+        const unsigned int grid = (unsigned int)std::min<uint64_t>(grid_for(n), persistent_grid(k, kBlock, cfg, lds));
         if (count_work)
-            hipLaunchKernelGGL((k_trace_two_level_persistent<true>), dim3(grid), dim3(kBlock), 0, st,
-                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, cfg.spill,
-                               cfg.spill_entries, counters);
+            hipLaunchKernelGGL((k_trace_two_level_persistent<true>), dim3(grid), dim3(kBlock), lds, st,
+                               s, rays, hits, (uint32_t)n, fixup, pp, counters);
         else
-            hipLaunchKernelGGL((k_trace_two_level_persistent<false>), dim3(grid), dim3(kBlock), 0, st,
-                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, cfg.spill,
-                               cfg.spill_entries, counters);
+            hipLaunchKernelGGL((k_trace_two_level_persistent<false>), dim3(grid), dim3(kBlock), lds, st,
+                               s, rays, hits, (uint32_t)n, fixup, pp, counters);
         return;
     }
     if (count_work)
@@ -302,20 +338,24 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
             }
             // on any failure the rays are simply taken in queue order
         }
-        static std::atomic<int> occ[2];
-        const void *k = count_work ? (const void *)k_trace_ordered_persistent<true>
-                                   : (const void *)k_trace_ordered_persistent<false>;
-        const unsigned int grid = (unsigned int)std::min<uint64_t>(
-            grid_for(n), persistent_grid(k, kBlock, cfg, &occ[count_work ? 1 : 0]));
+        const PersistentParams pp = persistent_params(cfg, s);
+        const unsigned int lds = persistent_lds_bytes(pp);
+        const bool cached = pp.cache_nodes > 0;
+        const void *k = count_work ? (cached ? (const void *)k_trace_ordered_persistent<true, true>
+                                             : (const void *)k_trace_ordered_persistent<true, false>)
+                                   : (cached ? (const void *)k_trace_ordered_persistent<false, true>
+                                             : (const void *)k_trace_ordered_persistent<false, false>);
+        const unsigned int grid = (unsigned int)std::min<uint64_t>(grid_for(n), persistent_grid(k, kBlock, cfg, lds));
         if (bracket) (void)hipEventRecord(bracket[0], st);
-        if (count_work)
-            hipLaunchKernelGGL((k_trace_ordered_persistent<true>), dim3(grid), dim3(kBlock), 0, st,
-                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, cfg.spill,
-                               cfg.spill_entries, counters, perm);
-        else
-            hipLaunchKernelGGL((k_trace_ordered_persistent<false>), dim3(grid), dim3(kBlock), 0, st,
-                               s, rays, hits, (uint32_t)n, fixup, cfg.refill, cfg.leaf_lanes, cfg.spill,
-                               cfg.spill_entries, counters, perm);
+#define PT_LAUNCH(C, L)                                                                             \
+    hipLaunchKernelGGL((k_trace_ordered_persistent<C, L>), dim3(grid), dim3(kBlock), lds, st, s, rays, \
+                       hits, (uint32_t)n, fixup, pp, counters, perm)
+        if (count_work) {
+            if (cached) PT_LAUNCH(true, true); else PT_LAUNCH(true, false);
+        } else {
+            if (cached) PT_LAUNCH(false, true); else PT_LAUNCH(false, false);
+        }
+#undef PT_LAUNCH
         if (bracket) (void)hipEventRecord(bracket[1], st);
         return;
     }
@@ -335,13 +375,12 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
     if (n == 0) return;
     if (s.tlas) {
         if (!exact_order && cfg.persistent_blocks > 0) {
-            static std::atomic<int> occ2{0};
+            const PersistentParams pp = persistent_params(cfg, s);
+            const unsigned int lds = persistent_lds_bytes(pp);
             const unsigned int grid = (unsigned int)std::min<uint64_t>(
-                grid_for(n),
-                persistent_grid((const void *)k_trace_any_two_level_persistent, kBlock, cfg, &occ2));
-            hipLaunchKernelGGL(k_trace_any_two_level_persistent, dim3(grid), dim3(kBlock), 0, st, s,
-                               rays, occluded, (uint32_t)n, cfg.refill, cfg.leaf_lanes, cfg.spill,
-                               cfg.spill_entries);
+                grid_for(n), persistent_grid((const void *)k_trace_any_two_level_persistent, kBlock, cfg, lds));
+            hipLaunchKernelGGL(k_trace_any_two_level_persistent, dim3(grid), dim3(kBlock), lds, st, s,
+                               rays, occluded, (uint32_t)n, pp);
             return;
         }
         hipLaunchKernelGGL(k_trace_any_two_level, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays,
@@ -350,11 +389,19 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
     }
     const bool wide = !exact_order && s.n_tri >= 2;
     if (wide && cfg.persistent_blocks > 0) {
-        static std::atomic<int> occ{0};
-        const unsigned int grid = (unsigned int)std::min<uint64_t>(
-            grid_for(n), persistent_grid((const void *)k_trace_any_persistent, kBlock, cfg, &occ));
-        hipLaunchKernelGGL(k_trace_any_persistent, dim3(grid), dim3(kBlock), 0, st, s, rays, occluded,
-                           (uint32_t)n, cfg.refill, cfg.leaf_lanes, cfg.spill, cfg.spill_entries);
+        const PersistentParams pp = persistent_params(cfg, s);
+        const unsigned int lds = persistent_lds_bytes(pp);
+        if (pp.cache_nodes > 0) {
+            const unsigned int grid = (unsigned int)std::min<uint64_t>(
+                grid_for(n), persistent_grid((const void *)k_trace_any_persistent<true>, kBlock, cfg, lds));
+            hipLaunchKernelGGL(k_trace_any_persistent<true>, dim3(grid), dim3(kBlock), lds, st, s, rays,
+                               occluded, (uint32_t)n, pp);
+        } else {
+            const unsigned int grid = (unsigned int)std::min<uint64_t>(
+                grid_for(n), persistent_grid((const void *)k_trace_any_persistent<false>, kBlock, cfg, lds));
+            hipLaunchKernelGGL(k_trace_any_persistent<false>, dim3(grid), dim3(kBlock), lds, st, s, rays,
+                               occluded, (uint32_t)n, pp);
+        }
         return;
     }
     hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays, occluded, n,

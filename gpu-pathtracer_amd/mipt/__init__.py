@@ -163,6 +163,7 @@ _PROTOS = {
     "pt_scene_read_mesh_nodes": (C.c_int, [_vp, C.c_uint32, _vp]),
     "pt_scene_node_count": (C.c_uint32, [_vp]),
     "pt_scene_link_encoding": (C.c_uint32, [_vp]),
+    "pt_scene_tree_depth": (C.c_uint32, [_vp]),
     "pt_scene_read_nodes": (C.c_int, [_vp, _vp]),
     "pt_trace_closest": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32,
                                    C.POINTER(TraceStats)]),
@@ -506,6 +507,9 @@ class Scene:
         out = np.empty(lib.pt_scene_mesh_node_count(self._h, mesh), dtype=bbox_dtype)
         _check(lib.pt_scene_read_mesh_nodes(self._h, mesh, _ptr(out)))
         return out
+
+    def tree_depth(self) -> int:
+        return int(lib.pt_scene_tree_depth(self._h))
 
     def read_nodes(self) -> np.ndarray:
         """The scene's skip-link node array."""

@@ -201,7 +201,13 @@ int pt_context_last_trace_ms(pt_context *ctx, double *ms);
  * "extend.refill" 1..64: idle lanes that trigger a refill (default 40);
  * "extend.leaf_lanes" 1..64: lanes waiting at a triangle that trigger a triangle step of the
  * wave (default 16); "extend.blocks_per_cu" 1..8: persistent workgroups per compute unit
- * (default 5); "any.exact_order" 0|1: occlusion queries walk the reference's skip links
+ * (default 5); "extend.stack_entries" -1|9..30 and "extend.cache_nodes" -1|0..448: how a
+ * persistent workgroup's LDS is split between the lanes' traversal stacks (entries per lane;
+ * rays that need more go on in global memory) and a copy of the first nodes of the tree,
+ * breadth first from the root, which the steps every ray takes first then read from LDS
+ * instead of through the vector memory pipeline (default -1: 16 entries + 224 nodes for trees
+ * up to 40 levels deep, 30 entries and no copy for deeper ones; single-level scenes only);
+ * "any.exact_order" 0|1: occlusion queries walk the reference's skip links
  * instead of the two-child nodes (default 0); "trace.sort_rays" -1|0|1: pt_trace_closest*
  * takes the rays in Morton order of their origins (default -1: when the scene exceeds the
  * 256 MB Infinity Cache and the call has at least 2^18 rays).  Results do not depend on any
@@ -312,6 +318,9 @@ int pt_scene_read_mesh_nodes(pt_scene *scene, uint32_t mesh, pt_bbox *nodes);
  * for validation, caching, or a CPU traversal of the same tree.  Blocking. */
 uint32_t pt_scene_node_count(const pt_scene *scene);
 uint32_t pt_scene_link_encoding(const pt_scene *scene);
+/* Levels of inner nodes below the root of a single-level scene's tree (what the per-scene choice
+ * of "extend.stack_entries" / "extend.cache_nodes" goes by). */
+uint32_t pt_scene_tree_depth(const pt_scene *scene);
 int pt_scene_read_nodes(pt_scene *scene, pt_bbox *nodes);
 int pt_scene_destroy(pt_scene *scene);
 

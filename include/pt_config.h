@@ -21,17 +21,33 @@
  * whose distances differ by less than this fraction are re-resolved in the
  * reference's fixed skip-link order.  2^-18. */
 #define PT_TIE_WINDOW 3.814697265625e-06f
-/* Per-lane entries of the LDS traversal stack: 31 x 4 B x 256 lanes with the sentinel, so that
- * five workgroups fit the 160 KB of a compute unit. */
+/* Per-lane entries of the LDS traversal stack of the one-thread-per-ray kernels, and the most a
+ * persistent kernel may be given: 31 x 4 B x 256 lanes with the sentinel, so that five
+ * workgroups fit the 160 KB of a compute unit. */
 #ifndef PT_LDS_STACK_ENTRIES
 #define PT_LDS_STACK_ENTRIES 30
+#endif
+/* Most two-child nodes from the top of the tree (breadth first from the root) that a scene
+ * prepares for the persistent traversal kernels to keep in LDS, so that the steps every ray
+ * takes first do not go through the vector memory pipeline.  How many a launch really keeps,
+ * and how many stack entries, is chosen per launch (options "extend.cache_nodes",
+ * "extend.stack_entries"). */
+#ifndef PT_LDS_NODE_CACHE_MAX
+#define PT_LDS_NODE_CACHE_MAX 448
+#endif
+/* Deepest tree (levels) for which the persistent kernels trade stack entries for cached nodes
+ * by default. */
+#ifndef PT_CACHE_MAX_TREE_DEPTH
+#define PT_CACHE_MAX_TREE_DEPTH 40
 #endif
 /* Lanes of a wave with a ray waiting for the fixed-order walk that start the walk for all. */
 #ifndef PT_TIE_BATCH
 #define PT_TIE_BATCH 16
 #endif
-/* Threads per workgroup of the traversal kernels (4 wave64). */
+/* Threads per workgroup of the traversal kernels (a multiple of 64). */
+#ifndef PT_TRACE_BLOCK
 #define PT_TRACE_BLOCK 256
+#endif
 
 /* ---- camera modes -------------------------------------------------------- */
 /* Reproduces shaders/depth.frag:47-83 literally, including its debug

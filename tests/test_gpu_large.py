@@ -8,6 +8,9 @@ through size-independent properties on everything.
   restatement walking the GPU-built tree.
 * config 2: Cornell box 1920x1080, 64 spp, depth 4, Lambertian: the whole frame on the GPU,
   a random subset of pixels recomputed by the CPU restatement.
+* config 3: Sponza-class scene (262 K triangles) 1920x1080, depth 8, Lambert + GGX: whole frames
+  (a few samples per pixel, the bench's own parameters) against the CPU restatement, every pixel,
+  without and with next-event estimation.
 """
 import numpy as np
 import pytest
@@ -191,4 +194,39 @@ def test_awkward_rays_match_the_oracle(mipt, oracle, scenes, gpu_ctx):
         assert (mt["uvwt"][:, 3].view(np.uint32) == 0x80000000).sum() == 0
     finally:
         gpu_ctx.set_option("extend.persistent", 1)
+        sc.close()
+
+
+def test_sponza_class_1080p_depth8_whole_frame(mipt, oracle, scenes, gpu_ctx):
+    """The benchmark's frame at its full size -- same scene, tree options, camera, depth, seed,
+    background and Russian-roulette depth as bench.py -- against the CPU restatement of the same
+    step: every bit of every pixel, the ray counts too.  Two samples per pixel without and one
+    with next-event estimation (27 M rays in all); with the default split of the workgroups'
+    LDS and with the whole of it given to the stacks."""
+    vtx, idx, mats, mids = scenes.atrium(262144, seed=42)
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx),
+                           mipt.bvh_options(**{"bvh.builder": "sah", "mipt.optimize_passes": "2"}))
+    W, H = 1920, 1080
+    cam = scenes.atrium_camera(W / H)
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx, mats, mids)
+    film = mipt.Film(gpu_ctx, W, H)
+    try:
+        for flags, spp in ((0, 2), (mipt.PT_RENDER_NEE, 1)):
+            p = mipt.render_params(W, H, sample_begin=16, sample_count=spp, max_depth=8, seed=42,
+                                   rr_start_depth=3, background=(0.55, 0.65, 0.8), flags=flags)
+            want, rays = oracle.render(nodes, vtx, idx, mats, mids, cam, p, nthreads=16)
+            for cache_nodes in (-1, 0):
+                gpu_ctx.set_option("extend.cache_nodes", cache_nodes)
+                gpu_ctx.set_option("extend.stack_entries", -1 if cache_nodes < 0 else 30)
+                film.clear()
+                st = mipt.render(gpu_ctx, sc, cam, p, film, stats=True)
+                assert st.rays_primary + st.rays_bounce + st.rays_shadow == rays
+                got = film.read()
+                diff = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=-1).sum())
+                assert diff == 0, f"{diff} of {W * H} pixels differ from the CPU restatement"
+            print(f"1080p depth 8 {'with' if flags else 'without'} NEE: {rays} rays, film bit-identical")
+    finally:
+        gpu_ctx.set_option("extend.cache_nodes", -1)
+        gpu_ctx.set_option("extend.stack_entries", -1)
+        film.close()
         sc.close()

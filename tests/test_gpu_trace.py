@@ -265,9 +265,17 @@ def test_stack_goes_on_in_global_memory(mipt, oracle, gpu_ctx, n):
     rays["d"][:, 0] = -1
     rays["d"][:, 1:3] = rng.uniform(-0.004, 0.004, (m, 2))
     rays["d"][::3, 1] = rng.uniform(0.01, 0.02, len(rays[::3]))        # grazing: these mostly miss
-    limit = 29 + 48        # pending nodes a lane can hold: LDS entries (one is kept free) + global slots
-    got, st = _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays,
-                               expect_ties=(lambda t: t == 0) if n - 1 <= limit else (lambda t: t > 0))
+    # pending nodes a lane can hold: LDS entries (one is kept free) + global slots.  The LDS
+    # entries are set by hand here; left alone the library picks 16 or 24 by the tree's depth,
+    # which the last round checks too (any number of re-resolved rays, same hits).
+    for entries in (30, 12, -1):
+        gpu_ctx.set_option("extend.stack_entries", entries)
+        try:
+            limit = entries - 1 + 48
+            expect = None if entries < 0 else ((lambda t: t == 0) if n - 1 <= limit else (lambda t: t > 0))
+            got, st = _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays, expect_ties=expect)
+        finally:
+            gpu_ctx.set_option("extend.stack_entries", -1)
     assert (got["primid"] >= 0).mean() > 0.3 and (got["primid"] < 0).mean() > 0.05
     sc = mipt.Scene(gpu_ctx, nodes, vtx, idx)
     try:
