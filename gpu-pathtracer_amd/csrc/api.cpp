@@ -66,9 +66,12 @@ ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bo
     c.refill = ctx->extend_refill;
     c.leaf_lanes = ctx->extend_leaf_lanes;
     c.sort_rays = 0;
+    c.sort_origin_bits = ctx->sort_origin_bits;
+    c.sort_dir_bits = ctx->sort_dir_bits;
     c.spill = (int32_t *)ctx->stack_spill.ptr;
     c.spill_entries = ctx->stack_spill.ptr ? kSpillEntries : 0;
     c.max_grid = 0;
+    c.xcd_slots = ctx->extend_xcd_slots > 0 ? 1 : 0;
     // The LDS of a persistent workgroup (measured on MI355X, 262 K-triangle scene in the caches
     // and 28 M-triangle scene beyond them):
     //  - a tree of moderate depth gets by with 16 stack entries per lane, and 224 cached nodes
@@ -385,6 +388,14 @@ int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
     } else if (k == "trace.sort_rays") {
         if (v < -1 || v > 1) return fail(PT_ERR_INVALID, "trace.sort_rays must be -1, 0 or 1");
         ctx->trace_sort_rays = (int)v;
+    } else if (k == "extend.xcd_slots") {
+        ctx->extend_xcd_slots = (int)v;
+    } else if (k == "trace.sort_origin_bits") {
+        if (v < 1 || v > 10) return fail(PT_ERR_INVALID, "trace.sort_origin_bits must be in [1,10]");
+        ctx->sort_origin_bits = (int)v;
+    } else if (k == "trace.sort_dir_bits") {
+        if (v < 0 || v > 8) return fail(PT_ERR_INVALID, "trace.sort_dir_bits must be in [0,8]");
+        ctx->sort_dir_bits = (int)v;
     } else if (k == "any.exact_order") {
         ctx->any_exact_order = v != 0;
     } else if (k == "extend.refill") {
@@ -518,8 +529,8 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     void *d_nodes, *d_vtx, *d_idx, *d_wn, *d_wt, *d_st, *d_mid, *d_mat, *d_lt = nullptr, *d_lc = nullptr;
-    if (wide.nodes.size() > (1u << 26) || wide.tris.size() > 89000000u)
-        return fail(PT_ERR_UNSUPPORTED, "pt_scene_create: scene too large for 32-bit record offsets");
+    if (wide.nodes.size() > kMaxWideNodes || wide.tris.size() > kMaxWideTris)
+        return fail(PT_ERR_UNSUPPORTED, "pt_scene_create: more nodes or triangle records than a child index can name");
     hipError_t e;
 #define UP(dst, src, bytes)                                                     \
     if ((e = upload(&dst, src, bytes)) != hipSuccess) {                         \
@@ -558,6 +569,7 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     d.n_materials = (uint32_t)mats.size();
     d.link_enc = link_encoding;
     d.wide_depth = wide.max_depth;
+    d.big = needs_big_addresses(wide.nodes.size(), wide.tris.size()) ? 1u : 0u;
     if (n_tri >= 2) {
         const int rc = attach_top_cache(ctx, sc.get());
         if (rc != PT_OK) return rc;
@@ -582,8 +594,8 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
         return fail(PT_ERR_INVALID,
                     "pt_scene_build: more than 2^24 nodes need PT_LINKS_INT_BITS (indices above "
                     "2^24 are not exact as float values)");
-    if (n_tri > 89000000u)
-        return fail(PT_ERR_UNSUPPORTED, "pt_scene_build: scene too large for 32-bit record offsets");
+    if (n_tri > kMaxWideTris)
+        return fail(PT_ERR_UNSUPPORTED, "pt_scene_build: more triangles than a child index can name");
     PT_TRY
     for (uint64_t i = 0; i < 3ull * n_tri; ++i)
         if (idx[i] < 0 || (uint32_t)idx[i] >= n_vtx)
@@ -690,6 +702,7 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
     d.n_materials = (uint32_t)mats.size();
     d.link_enc = link_encoding;
     d.wide_depth = br.max_depth;
+    d.big = needs_big_addresses(n_tri - 1, n_tri) ? 1u : 0u;
     {
         const int rc = attach_top_cache(ctx, sc.get());
         if (rc != PT_OK) return rc;

@@ -157,9 +157,9 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             pl.vtx = (uint32_t)tot_vtx; pl.tri = (uint32_t)tot_tri;
             tot_nodes += pl.n_nodes; tot_wnodes += pl.n_wnodes; tot_wtris += pl.n_wtris;
             tot_vtx += d.n_vertices; tot_tri += d.n_triangles;
-            if (tot_wnodes > (1u << 26) || tot_wtris > 89000000u)
+            if (tot_wnodes > kMaxWideNodes || tot_wtris > kMaxWideTris)
                 return fail(PT_ERR_UNSUPPORTED,
-                            "pt_scene_create_instanced: meshes too large together for 32-bit record offsets");
+                            "pt_scene_create_instanced: more nodes or triangle records than a child index can name");
             if (tot_nodes > 0x7fffffffull || tot_vtx > 0x7fffffffull)
                 return fail(PT_ERR_UNSUPPORTED, "pt_scene_create_instanced: meshes too large together");
         }
@@ -419,6 +419,7 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
         d.n_materials = (uint32_t)mats.size();
         d.link_enc = link_encoding;
         d.wide_depth = wide_depth;
+        d.big = needs_big_addresses(tot_wnodes, tot_wtris) ? 1u : 0u;
         d.tlas = (const float4 *)upload(top_nodes, sizeof(pt_bbox) * (size_t)n_top_nodes);
         {
             std::vector<WideNode> wtop;

@@ -38,6 +38,9 @@ struct pt_context {
     int extend_stack_entries = -1;  // option "extend.stack_entries" (-1: chosen per scene)
     int extend_cache_nodes = -1;    // option "extend.cache_nodes" (-1: chosen per scene)
     int any_exact_order = 0;        // option "any.exact_order"
+    int extend_xcd_slots = 0;       // option "extend.xcd_slots"
+    int sort_origin_bits = 10;      // option "trace.sort_origin_bits"
+    int sort_dir_bits = 0;          // option "trace.sort_dir_bits"
     int trace_sort_rays = -1;       // option "trace.sort_rays": 0 off, 1 on, -1 by scene size
     int build_ploc_radius = 0;      // option "build.ploc_radius": 0 = radix tree, else clustering
     int build_optimize_passes = 0;  // option "build.optimize_passes": insertion-based optimisation rounds

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <atomic>
 
 #include "../../include/mipt.h"
@@ -44,6 +45,7 @@ struct DeviceScene {
     uint32_t n_nodes, n_tri, n_wnodes, n_materials;
     uint32_t link_enc;
     uint32_t wide_depth;
+    uint32_t big;          // wnodes or wtris reach beyond 4 GiB: records need 64-bit addresses
     // Single-level scenes: the first n_top_cache two-child nodes in breadth-first order from the
     // root, as the persistent kernels copy them to LDS.  A child that lies in this array itself
     // is named kLdsNodeBase + its position here; other children as in wnodes.
@@ -61,6 +63,12 @@ struct DeviceScene {
 };
 
 constexpr int32_t kLdsNodeBase = 1 << 30;
+// What the child encodings can name: two-child nodes below kLdsNodeBase, triangle records by
+// their position in 16-byte units (three per record) in 31 bits.
+constexpr uint64_t kMaxWideNodes = (1ull << 30) - 1, kMaxWideTris = 700000000ull;
+inline bool needs_big_addresses(uint64_t n_wnodes, uint64_t n_wtris) {
+    return n_wnodes > (1ull << 26) || n_wtris > 89000000ull;
+}
 constexpr int kNodeCacheMax = PT_LDS_NODE_CACHE_MAX;
 // Fills top_cache and top_global (room for kNodeCacheMax nodes each) from wnodes and writes the
 // number of nodes to *n_out.
@@ -74,6 +82,7 @@ struct PersistentParams {
     int spill_entries;
     int stack_cap;      // per-lane LDS stack entries (without the bottom sentinel)
     int cache_nodes;    // nodes of the scene's top_cache a workgroup keeps in LDS
+    int xcd_slots;      // deal every round's chunks to the XCDs in contiguous eighths
 };
 
 // Device counters of a trace call (mirrors pt_trace_stats, device side).
@@ -93,6 +102,8 @@ struct ExtendConfig {
     int refill;             // persistent form: top up a wave when this many lanes are idle
     int leaf_lanes;         // persistent form: triangle step once this many lanes wait at one
     int sort_rays;          // trace calls, persistent form: take the rays in origin-cell order
+    int sort_origin_bits;   // bits per axis of the origin cell in the sort key (<= 10)
+    int sort_dir_bits;      // bits per octahedral coordinate of the direction in the key (0: none)
     // persistent form: global memory for the stack entries of rays that need more than the LDS
     // holds, spill_entries slots for each lane of the largest grid (kSpillEntries, or 0)
     int32_t *spill;
@@ -101,6 +112,7 @@ struct ExtendConfig {
     // the tree every workgroup keeps in LDS (single-level scenes; 0: none)
     int stack_entries;
     int cache_nodes;
+    int xcd_slots;          // see PersistentParams
     // persistent form: upper bound on the grid in workgroups (0: none), for a spill area that
     // was sized for fewer lanes than the device could keep resident
     unsigned int max_grid;
@@ -167,7 +179,19 @@ inline PersistentParams persistent_params(const ExtendConfig &cfg, const DeviceS
     pp.stack_cap = cfg.stack_entries;
     pp.cache_nodes = s.tlas ? 0 : (int)(cfg.cache_nodes < (int)s.n_top_cache ? cfg.cache_nodes : s.n_top_cache);
     if (pp.cache_nodes < 0) pp.cache_nodes = 0;
+    pp.xcd_slots = cfg.xcd_slots;
     return pp;
+}
+
+// Launch of a persistent kernel given as a function pointer (the template arguments are picked
+// by the caller): grid sized to what can be resident, dynamic LDS as the loop parameters say.
+template <class... KArgs, class... Args>
+inline void launch_persistent(void (*kernel)(KArgs...), hipStream_t st, uint64_t n_blocks_wanted,
+                       const ExtendConfig &cfg, const PersistentParams &pp, Args... args) {
+    const unsigned int lds = persistent_lds_bytes(pp);
+    const unsigned int grid = (unsigned int)std::min<uint64_t>(
+        n_blocks_wanted, persistent_grid((const void *)kernel, PT_TRACE_BLOCK, cfg, lds));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PT_TRACE_BLOCK), lds, st, args...);
 }
 
 // Occlusion query.  exact_order: walk the skip links as the reference does; otherwise the

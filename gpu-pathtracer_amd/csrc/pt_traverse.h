@@ -157,13 +157,20 @@ __device__ __forceinline__ void traverse_skiplink(const DeviceScene &s, const fl
     }
 }
 
-// Records of the re-laid-out scene by 32-bit byte offset from a uniform base (one scalar
-// base + one vector offset per load); pt_scene_create keeps both arrays below 4 GiB.
+// Records of the re-laid-out scene.  BIG = false: by 32-bit byte offset from a uniform base (one
+// scalar base + one vector offset per load), for scenes whose arrays stay below 4 GiB (2^26
+// two-child nodes, 89 M triangle records); BIG = true: 64-bit address arithmetic per lane, for
+// scenes beyond that.  The persistent kernels are compiled both ways and the scene says which
+// to launch (DeviceScene::big); the one-thread-per-ray forms always take the 64-bit form.
+template <bool BIG = true>
 __device__ __forceinline__ const float4 *wide_node(const DeviceScene &s, int32_t node) {
+    if (BIG) return s.wnodes + 4 * (size_t)(uint32_t)node;
     return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wnodes) +
                                             ((uint32_t)node << 6));
 }
+template <bool BIG = true>
 __device__ __forceinline__ const float4 *wide_tri(const DeviceScene &s, int32_t leaf) {
+    if (BIG) return s.wtris + (size_t)(uint32_t)(~leaf);
     return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wtris) +
                                             ((uint32_t)(~leaf) << 4));
 }
@@ -350,7 +357,7 @@ __device__ __forceinline__ void any_begin(OrderedState &st, const float4 ro, con
 // only divergent regions are the stack accesses and the work inside the triangle test.
 // ANY: occlusion query -- the triangle step is the Moller-Trumbore test of
 // shaders/RadeonRays/bvh.glslh:289-310 and the first hit ends the ray.
-template <bool COUNT, bool ANY = false, bool CACHE = false>
+template <bool COUNT, bool ANY = false, bool CACHE = false, bool BIG = false>
 __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedState &st,
                                                 int32_t *stack, int min_active, int leaf_lanes,
                                                 unsigned long long &nb, unsigned long long &nt,
@@ -378,7 +385,7 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                     a = np[0]; b = np[1]; c = np[2];
                     ch = reinterpret_cast<const int4 *>(np)[3];
                 } else {
-                    const float4 *np = wide_node(s, st.cur);
+                    const float4 *np = wide_node<BIG>(s, st.cur);
                     a = np[0]; b = np[1]; c = np[2];
                     ch = reinterpret_cast<const int4 *>(np)[3];
                 }
@@ -410,7 +417,7 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
         }
         if (mode == 2) return;
         if (at_leaf) {
-            const float4 *tp = wide_tri(s, st.cur);
+            const float4 *tp = wide_tri<BIG>(s, st.cur);
             const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
 #ifdef PT_WAVE_ITERS
             if (COUNT && (__ffsll(__ballot(1)) - 1) == (int)(threadIdx.x & 63)) nt += 64;
@@ -765,7 +772,7 @@ struct HitSink {
 // drains.  ANY = false: closest hits, sink(ray, shapeid, primid, b0, b1, b2, t).
 // ANY = true: occlusion queries, sink(ray, occluded).  perm, if not null, is the order in
 // which to take the rays (queue position -> ray index); sinks always get the ray index.
-template <bool COUNT, bool ANY, bool CACHE, class Sink>
+template <bool COUNT, bool ANY, bool CACHE, bool BIG, class Sink>
 __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const pt_ray *rays,
                                                     uint32_t n, bool fixup, const PersistentParams pp,
                                                     unsigned int *tie_count,
@@ -802,7 +809,17 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
         (int)(blockIdx.x * (kTraceBlock / 64) + (threadIdx.x >> 6)));
     const uint32_t n_waves = gridDim.x * (kTraceBlock / 64);
     const uint32_t n_chunks = (n + 63u) >> 6;
-    const uint32_t owned = wave < n_chunks ? (n_chunks - wave + n_waves - 1) / n_waves : 0;
+    // Which chunk of every round of n_waves chunks is this wave's.  Plainly its own index; or,
+    // with xcd_slots, such that the workgroups of one XCD (blockIdx % 8) take one contiguous
+    // eighth of the round: neighbouring chunks of an ordered queue then meet in one L2 instead
+    // of all eight, while every round is still spread over the whole machine.
+    uint32_t slot = wave;
+    if (pp.xcd_slots && (gridDim.x & 7u) == 0u) {
+        constexpr uint32_t wpb = kTraceBlock / 64;
+        const uint32_t block = wave / wpb;
+        slot = (block & 7u) * (n_waves >> 3) + (block >> 3) * wpb + (wave % wpb);
+    }
+    const uint32_t owned = slot < n_chunks ? (n_chunks - slot + n_waves - 1) / n_waves : 0;
     const uint32_t stream_len = owned << 6;     // positions in this wave's stream
     uint32_t pos = 0;                           // next unread position (wave-uniform)
     constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -905,7 +922,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
         if (pos < stream_len && m) {                            // top up idle lanes
             const uint32_t p = pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (idle && p < stream_len) {
-                const uint32_t idx = (((p >> 6) * n_waves + wave) << 6) + (p & 63u);
+                const uint32_t idx = (((p >> 6) * n_waves + slot) << 6) + (p & 63u);
                 if (idx < n) {
                     const uint32_t ri = perm ? perm[idx] : idx;
                     const float4 ro = reinterpret_cast<const float4 *>(rays + ri)[0];
@@ -922,8 +939,8 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
             if (pos >= stream_len) break;
             continue;                                           // tail positions past the queue end
         }
-        ordered_advance<COUNT, ANY, CACHE>(s, st, stack, pos < stream_len ? 64 - refill : 0, leaf_lanes,
-                                           nb, nt, stack_cap, cache);
+        ordered_advance<COUNT, ANY, CACHE, BIG>(s, st, stack, pos < stream_len ? 64 - refill : 0,
+                                                leaf_lanes, nb, nt, stack_cap, cache);
     }
     if constexpr (!ANY) walk_parked();
     if (!ANY && n_ties) atomicAdd(tie_count, n_ties);
@@ -954,7 +971,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
 //
 // Every service moves a lane's top-level walk forward or retires its ray, and every wave's
 // stream is finite: the grid drains.
-template <bool COUNT, bool ANY, class Sink>
+template <bool COUNT, bool ANY, bool BIG, class Sink>
 __device__ __forceinline__ void persistent_traverse_two_level(
     const DeviceScene &s, const pt_ray *rays, uint32_t n, bool fixup, const PersistentParams pp,
     unsigned int *tie_count, DeviceTraceCounters *work, Sink sink) {
@@ -1134,7 +1151,7 @@ __device__ __forceinline__ void persistent_traverse_two_level(
             continue;                                           // lanes waiting for service only
         }
         const int batch = min(refill, max(1, active >> 1));
-        ordered_advance<COUNT, ANY>(s, st, stack, active - batch, leaf_lanes, nb, nt, stack_cap);
+        ordered_advance<COUNT, ANY, false, BIG>(s, st, stack, active - batch, leaf_lanes, nb, nt, stack_cap);
     }
     if (!ANY && n_ties) atomicAdd(tie_count, n_ties);
     if (COUNT) {
@@ -1147,14 +1164,14 @@ __device__ __forceinline__ void persistent_traverse_two_level(
     }
 }
 
-template <bool COUNT, bool CACHE>
+template <bool COUNT, bool CACHE, bool BIG>
 __device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, const pt_ray *rays,
                                                         pt_hit *hits, uint32_t n, bool fixup,
                                                         const PersistentParams pp,
                                                         unsigned int *tie_count,
                                                         DeviceTraceCounters *work,
                                                         const uint32_t *perm = nullptr) {
-    persistent_traverse<COUNT, false, CACHE>(s, rays, n, fixup, pp, tie_count, work, HitSink{hits}, perm);
+    persistent_traverse<COUNT, false, CACHE, BIG>(s, rays, n, fixup, pp, tie_count, work, HitSink{hits}, perm);
 }
 
 // Compacting append to a queue: every lane with `keep` gets a distinct slot.  One atomic

@@ -124,11 +124,11 @@ __global__ __launch_bounds__(kBlock) void k_pt_extend_two_level(DeviceScene s, c
     }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool BIG>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_two_level_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, const unsigned int *count,
     unsigned int *tie_count, DeviceTraceCounters *work, PersistentParams pp) {
-    persistent_traverse_two_level<COUNT, false>(s, rays, *count, true, pp, tie_count, work, HitSink{hits});
+    persistent_traverse_two_level<COUNT, false, BIG>(s, rays, *count, true, pp, tie_count, work, HitSink{hits});
 }
 
 // extend, persistent form: the grid is sized to the machine, not to the queue.  Queue
@@ -136,11 +136,11 @@ __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_two_l
 // static, so no work-distribution atomics), and a wave tops its idle lanes up from its own
 // stream whenever `refill` or more of them have finished, instead of idling them until its
 // slowest ray ends.
-template <bool COUNT, bool CACHE>
+template <bool COUNT, bool CACHE, bool BIG>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, const unsigned int *count,
     unsigned int *tie_count, DeviceTraceCounters *work, PersistentParams pp) {
-    persistent_closest_hits<COUNT, CACHE>(s, rays, hits, *count, true, pp, tie_count, work);
+    persistent_closest_hits<COUNT, CACHE, BIG>(s, rays, hits, *count, true, pp, tie_count, work);
 }
 
 // shade: one path vertex per queued hit; survivors are appended to the next queue.
@@ -274,17 +274,18 @@ __global__ __launch_bounds__(kBlock) void k_pt_occlude_two_level(DeviceScene s, 
     ShadowSink{ws.shadow_carry, ws.radiance}((uint32_t)i, occ);
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_two_level_persistent(
     DeviceScene s, RenderWorkspace ws, const unsigned int *count, PersistentParams pp) {
-    persistent_traverse_two_level<false, true>(s, ws.shadow_rays, *count, true, pp, nullptr, nullptr,
+    persistent_traverse_two_level<false, true, BIG>(s, ws.shadow_rays, *count, true, pp, nullptr, nullptr,
                                                ShadowSink{ws.shadow_carry, ws.radiance});
 }
 
 // Persistent waves with lane refill and step voting, as the closest-hit kernel.
-template <bool CACHE>
+template <bool CACHE, bool BIG>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_persistent(
     DeviceScene s, RenderWorkspace ws, const unsigned int *count, PersistentParams pp) {
-    persistent_traverse<false, true, CACHE>(s, ws.shadow_rays, *count, true, pp, nullptr, nullptr,
+    persistent_traverse<false, true, CACHE, BIG>(s, ws.shadow_rays, *count, true, pp, nullptr, nullptr,
                                             ShadowSink{ws.shadow_carry, ws.radiance});
 }
 
@@ -353,18 +354,11 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
                       DeviceTraceCounters *work, const ExtendConfig &cfg) {
     if (!max_rays) return;
     const PersistentParams pp = persistent_params(cfg, s);
-    const unsigned int lds = persistent_lds_bytes(pp);
     if (s.tlas && cfg.persistent_blocks > 0) {
-        const void *k = work ? (const void *)k_pt_extend_two_level_persistent<true>
-                             : (const void *)k_pt_extend_two_level_persistent<false>;
-        const unsigned int grid = (unsigned int)std::min<uint64_t>(blocks(max_rays, kBlock),
-                                                                   persistent_grid(k, kBlock, cfg, lds));
-        if (work)
-            hipLaunchKernelGGL(k_pt_extend_two_level_persistent<true>, dim3(grid), dim3(kBlock), lds, st,
-                               s, ws.rays[buf], ws.hits, count, tie_count, work, pp);
-        else
-            hipLaunchKernelGGL(k_pt_extend_two_level_persistent<false>, dim3(grid), dim3(kBlock), lds, st,
-                               s, ws.rays[buf], ws.hits, count, tie_count, work, pp);
+        auto k = work ? (s.big ? k_pt_extend_two_level_persistent<true, true> : k_pt_extend_two_level_persistent<true, false>)
+                      : (s.big ? k_pt_extend_two_level_persistent<false, true> : k_pt_extend_two_level_persistent<false, false>);
+        launch_persistent(k, st, blocks(max_rays, kBlock), cfg, pp, s, (const pt_ray *)ws.rays[buf], ws.hits, count,
+                          tie_count, work, pp);
         return;
     }
     if (s.tlas) {
@@ -377,22 +371,17 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
         return;
     }
     if (cfg.persistent_blocks > 0) {
-        const bool cached = pp.cache_nodes > 0;
-        const void *k = work ? (cached ? (const void *)k_pt_extend_persistent<true, true>
-                                       : (const void *)k_pt_extend_persistent<true, false>)
-                             : (cached ? (const void *)k_pt_extend_persistent<false, true>
-                                       : (const void *)k_pt_extend_persistent<false, false>);
-        const unsigned int grid = (unsigned int)std::min<uint64_t>(blocks(max_rays, kBlock),
-                                                                   persistent_grid(k, kBlock, cfg, lds));
-#define PT_LAUNCH(C, L)                                                                               \
-    hipLaunchKernelGGL((k_pt_extend_persistent<C, L>), dim3(grid), dim3(kBlock), lds, st, s, ws.rays[buf], \
-                       ws.hits, count, tie_count, work, pp)
-        if (work) {
-            if (cached) PT_LAUNCH(true, true); else PT_LAUNCH(true, false);
-        } else {
-            if (cached) PT_LAUNCH(false, true); else PT_LAUNCH(false, false);
-        }
-#undef PT_LAUNCH
+        // template arguments: counting, cached top of the tree, 64-bit record addresses
+        using K = void (*)(DeviceScene, const pt_ray *, pt_hit *, const unsigned int *, unsigned int *,
+                           DeviceTraceCounters *, PersistentParams);
+        static const K table[8] = {
+            k_pt_extend_persistent<false, false, false>, k_pt_extend_persistent<false, false, true>,
+            k_pt_extend_persistent<false, true, false>,  k_pt_extend_persistent<false, true, true>,
+            k_pt_extend_persistent<true, false, false>,  k_pt_extend_persistent<true, false, true>,
+            k_pt_extend_persistent<true, true, false>,   k_pt_extend_persistent<true, true, true>};
+        const K k = table[(work ? 4 : 0) | (pp.cache_nodes > 0 ? 2 : 0) | (s.big ? 1 : 0)];
+        launch_persistent(k, st, blocks(max_rays, kBlock), cfg, pp, s, (const pt_ray *)ws.rays[buf], ws.hits, count,
+                          tie_count, work, pp);
         return;
     }
     if (work)
@@ -417,13 +406,9 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
                        const ExtendConfig &cfg) {
     if (!max_rays) return;
     const PersistentParams pp = persistent_params(cfg, s);
-    const unsigned int lds = persistent_lds_bytes(pp);
     if (s.tlas && cfg.persistent_blocks > 0) {
-        const unsigned int grid = (unsigned int)std::min<uint64_t>(
-            blocks(max_rays, kBlock),
-            persistent_grid((const void *)k_pt_occlude_two_level_persistent, kBlock, cfg, lds));
-        hipLaunchKernelGGL(k_pt_occlude_two_level_persistent, dim3(grid), dim3(kBlock), lds, st, s, ws,
-                           shadow_count, pp);
+        launch_persistent(s.big ? k_pt_occlude_two_level_persistent<true> : k_pt_occlude_two_level_persistent<false>,
+                          st, blocks(max_rays, kBlock), cfg, pp, s, ws, shadow_count, pp);
         return;
     }
     if (s.tlas) {
@@ -432,19 +417,11 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
         return;
     }
     if (cfg.persistent_blocks > 0 && s.n_tri >= 2) {
-        if (pp.cache_nodes > 0) {
-            const unsigned int grid = (unsigned int)std::min<uint64_t>(
-                blocks(max_rays, kBlock),
-                persistent_grid((const void *)k_pt_occlude_persistent<true>, kBlock, cfg, lds));
-            hipLaunchKernelGGL(k_pt_occlude_persistent<true>, dim3(grid), dim3(kBlock), lds, st, s, ws,
-                               shadow_count, pp);
-        } else {
-            const unsigned int grid = (unsigned int)std::min<uint64_t>(
-                blocks(max_rays, kBlock),
-                persistent_grid((const void *)k_pt_occlude_persistent<false>, kBlock, cfg, lds));
-            hipLaunchKernelGGL(k_pt_occlude_persistent<false>, dim3(grid), dim3(kBlock), lds, st, s, ws,
-                               shadow_count, pp);
-        }
+        using K = void (*)(DeviceScene, RenderWorkspace, const unsigned int *, PersistentParams);
+        static const K table[4] = {k_pt_occlude_persistent<false, false>, k_pt_occlude_persistent<false, true>,
+                                   k_pt_occlude_persistent<true, false>, k_pt_occlude_persistent<true, true>};
+        launch_persistent(table[(pp.cache_nodes > 0 ? 2 : 0) | (s.big ? 1 : 0)], st, blocks(max_rays, kBlock), cfg,
+                          pp, s, ws, shadow_count, pp);
         return;
     }
     hipLaunchKernelGGL(k_pt_occlude, dim3(blocks(max_rays, kBlock)), dim3(kBlock), 0, st, s, ws,

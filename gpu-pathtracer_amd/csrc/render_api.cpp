@@ -218,11 +218,13 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
     HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
 
-    // Samples in flight together: enough paths to fill the GPU many times over, bounded so
-    // the workspace stays around a gigabyte.
+    // Samples in flight together: the persistent closest-hit launches end with a tail in which
+    // few waves still have work, and the longer the queue the less that tail weighs (1080p on
+    // MI355X: 4 / 8 / 16 samples per pass give 4.26 / 4.52 / 4.66 Grays/s).  32 M paths are a
+    // 4.5 GB workspace, little on a 288 GB device.
     uint32_t spp_pass = p.samples_per_pass;
     if (spp_pass == 0) {
-        const uint64_t target_paths = 8ull << 20;
+        const uint64_t target_paths = 32ull << 20;
         spp_pass = (uint32_t)std::max<uint64_t>(1, target_paths / rl.map.n_local);
     }
     spp_pass = std::min(spp_pass, p.sample_count);

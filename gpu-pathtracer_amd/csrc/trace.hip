@@ -71,11 +71,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_ordered(DeviceScene s, const p
     }
 }
 
-template <bool COUNT, bool CACHE>
+template <bool COUNT, bool CACHE, bool BIG>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_ordered_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, uint32_t n, bool fixup, PersistentParams pp,
     DeviceTraceCounters *counters, const uint32_t *perm) {
-    persistent_closest_hits<COUNT, CACHE>(s, rays, hits, n, fixup, pp, &counters->tie_count, counters, perm);
+    persistent_closest_hits<COUNT, CACHE, BIG>(s, rays, hits, n, fixup, pp, &counters->tie_count, counters, perm);
 }
 
 // IntersectSceneAny, shaders/RadeonRays/bvh.glslh:378-414 (leaf test :350-375, :289-310).
@@ -99,10 +99,10 @@ struct OccludedSink {
         out[ray] = occluded ? 1 : 0;
     }
 };
-template <bool CACHE>
+template <bool CACHE, bool BIG>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_persistent(
     DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, PersistentParams pp) {
-    persistent_traverse<false, true, CACHE>(s, rays, n, true, pp, nullptr, nullptr, OccludedSink{occluded});
+    persistent_traverse<false, true, CACHE, BIG>(s, rays, n, true, pp, nullptr, nullptr, OccludedSink{occluded});
 }
 
 // Two-level scenes: one thread per ray (see closest_hit_two_level).
@@ -147,16 +147,17 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_two_level(DeviceScene s, c
 }
 
 // Two-level scenes by persistent waves (see persistent_traverse_two_level).
-template <bool COUNT>
+template <bool COUNT, bool BIG>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_two_level_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, uint32_t n, bool fixup, PersistentParams pp,
     DeviceTraceCounters *counters) {
-    persistent_traverse_two_level<COUNT, false>(s, rays, n, fixup, pp, &counters->tie_count, counters,
+    persistent_traverse_two_level<COUNT, false, BIG>(s, rays, n, fixup, pp, &counters->tie_count, counters,
                                                 HitSink{hits});
 }
+template <bool BIG>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_two_level_persistent(
     DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, PersistentParams pp) {
-    persistent_traverse_two_level<false, true>(s, rays, n, true, pp, nullptr, nullptr,
+    persistent_traverse_two_level<false, true, BIG>(s, rays, n, true, pp, nullptr, nullptr,
                                                OccludedSink{occluded});
 }
 
@@ -171,21 +172,44 @@ __device__ __forceinline__ unsigned int spread10(unsigned int v) {
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
+// ob: bits per axis of the origin cell (<= 10); db: bits per axis of the direction, as a point of
+// the octahedral map of the sphere (0: origin only).  The origin cell is the major part of the
+// key: rays of one cell come out grouped by direction.
 __global__ __launch_bounds__(kBlock) void k_ray_keys(DeviceScene s, const pt_ray *rays, uint32_t n,
-                                                     unsigned int *keys, uint32_t *vals) {
+                                                     unsigned int *keys, uint32_t *vals, int ob, int db) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 lo = s.nodes[0], hi = s.nodes[1];
     const float4 o = reinterpret_cast<const float4 *>(rays + i)[0];
     const float p[3] = {o.x, o.y, o.z}, a[3] = {lo.x, lo.y, lo.z}, b[3] = {hi.x, hi.y, hi.z};
     unsigned int q[3];
+    const float cells = (float)(1u << ob);
     for (int k = 0; k < 3; ++k) {
         const float ext = b[k] - a[k];
         float x = ext > 0.f ? (p[k] - a[k]) / ext : 0.f;
-        x = fminf(fmaxf(x * 1024.f, 0.f), 1023.f);      // NaN -> 0
+        x = fminf(fmaxf(x * cells, 0.f), cells - 1.f);      // NaN -> 0
         q[k] = (unsigned int)x;
     }
-    keys[i] = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+    unsigned int key = ((spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2])) & ((1u << (3 * ob)) - 1u);
+    if (db > 0) {
+        const float4 d = reinterpret_cast<const float4 *>(rays + i)[1];
+        const float l1 = fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
+        float u = l1 > 0.f ? d.x / l1 : 0.f, v = l1 > 0.f ? d.y / l1 : 0.f;
+        if (d.z < 0.f) {                                     // fold the lower hemisphere outwards
+            const float fu = (1.f - fabsf(v)) * (u >= 0.f ? 1.f : -1.f);
+            const float fv = (1.f - fabsf(u)) * (v >= 0.f ? 1.f : -1.f);
+            u = fu; v = fv;
+        }
+        const float bins = (float)(1u << db);
+        const unsigned int qu = (unsigned int)fminf(fmaxf((u * 0.5f + 0.5f) * bins, 0.f), bins - 1.f);
+        const unsigned int qv = (unsigned int)fminf(fmaxf((v * 0.5f + 0.5f) * bins, 0.f), bins - 1.f);
+        // the two direction coordinates interleaved, so that neighbours in the key are neighbours
+        // on the sphere
+        unsigned int dm = 0;
+        for (int k = 0; k < db; ++k) dm |= (((qu >> k) & 1u) << (2 * k + 1)) | (((qv >> k) & 1u) << (2 * k));
+        key = (key << (2 * db)) | dm;
+    }
+    keys[i] = key;
     vals[i] = i;
 }
 
@@ -287,16 +311,9 @@ void launch_trace_two_level(hipStream_t st, const DeviceScene &s, const pt_ray *
     if (n == 0) return;
     if (!exact && cfg.persistent_blocks > 0) {
         const PersistentParams pp = persistent_params(cfg, s);
-        const unsigned int lds = persistent_lds_bytes(pp);
-        const void *k = count_work ? (const void *)k_trace_two_level_persistent<true>
-                                   : (const void *)k_trace_two_level_persistent<false>;
-        const unsigned int grid = (unsigned int)std::min<uint64_t>(grid_for(n), persistent_grid(k, kBlock, cfg, lds));
-        if (count_work)
-            hipLaunchKernelGGL((k_trace_two_level_persistent<true>), dim3(grid), dim3(kBlock), lds, st,
-                               s, rays, hits, (uint32_t)n, fixup, pp, counters);
-        else
-            hipLaunchKernelGGL((k_trace_two_level_persistent<false>), dim3(grid), dim3(kBlock), lds, st,
-                               s, rays, hits, (uint32_t)n, fixup, pp, counters);
+        auto k = count_work ? (s.big ? k_trace_two_level_persistent<true, true> : k_trace_two_level_persistent<true, false>)
+                            : (s.big ? k_trace_two_level_persistent<false, true> : k_trace_two_level_persistent<false, false>);
+        launch_persistent(k, st, grid_for(n), cfg, pp, s, rays, hits, (uint32_t)n, fixup, pp, counters);
         return;
     }
     if (count_work)
@@ -322,40 +339,38 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
         const uint32_t *perm = nullptr;
         if (cfg.sort_rays && sort_scratch) {
             size_t sort_bytes = 0;
+            const int ob = std::min(10, std::max(1, cfg.sort_origin_bits));
+            const int db = std::min((32 - 3 * ob) / 2, std::max(0, cfg.sort_dir_bits));
+            const int key_bits = 3 * ob + 2 * db;
             hipError_t e = hipcub::DeviceRadixSort::SortPairs(
                 nullptr, sort_bytes, (unsigned int *)nullptr, (unsigned int *)nullptr,
-                (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 30, st);
+                (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, key_bits, st);
             const size_t arr = (4 * (size_t)n + 255) / 256 * 256;
             if (e == hipSuccess && sort_scratch->reserve(4 * arr + sort_bytes) == PT_OK) {
                 char *base = (char *)sort_scratch->ptr;
                 unsigned int *k0 = (unsigned int *)base, *k1 = (unsigned int *)(base + arr);
                 uint32_t *v0 = (uint32_t *)(base + 2 * arr), *v1 = (uint32_t *)(base + 3 * arr);
                 hipLaunchKernelGGL(k_ray_keys, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays,
-                                   (uint32_t)n, k0, v0);
+                                   (uint32_t)n, k0, v0, ob, db);
                 e = hipcub::DeviceRadixSort::SortPairs(base + 4 * arr, sort_bytes, k0, k1, v0, v1,
-                                                       (int)n, 0, 30, st);
+                                                       (int)n, 0, key_bits, st);
                 if (e == hipSuccess) perm = v1;
             }
             // on any failure the rays are simply taken in queue order
         }
         const PersistentParams pp = persistent_params(cfg, s);
-        const unsigned int lds = persistent_lds_bytes(pp);
         const bool cached = pp.cache_nodes > 0;
-        const void *k = count_work ? (cached ? (const void *)k_trace_ordered_persistent<true, true>
-                                             : (const void *)k_trace_ordered_persistent<true, false>)
-                                   : (cached ? (const void *)k_trace_ordered_persistent<false, true>
-                                             : (const void *)k_trace_ordered_persistent<false, false>);
-        const unsigned int grid = (unsigned int)std::min<uint64_t>(grid_for(n), persistent_grid(k, kBlock, cfg, lds));
+        // template arguments: counting, cached top of the tree, 64-bit record addresses
+        using K = void (*)(DeviceScene, const pt_ray *, pt_hit *, uint32_t, bool, PersistentParams,
+                           DeviceTraceCounters *, const uint32_t *);
+        static const K table[8] = {
+            k_trace_ordered_persistent<false, false, false>, k_trace_ordered_persistent<false, false, true>,
+            k_trace_ordered_persistent<false, true, false>,  k_trace_ordered_persistent<false, true, true>,
+            k_trace_ordered_persistent<true, false, false>,  k_trace_ordered_persistent<true, false, true>,
+            k_trace_ordered_persistent<true, true, false>,   k_trace_ordered_persistent<true, true, true>};
+        const K k = table[(count_work ? 4 : 0) | (cached ? 2 : 0) | (s.big ? 1 : 0)];
         if (bracket) (void)hipEventRecord(bracket[0], st);
-#define PT_LAUNCH(C, L)                                                                             \
-    hipLaunchKernelGGL((k_trace_ordered_persistent<C, L>), dim3(grid), dim3(kBlock), lds, st, s, rays, \
-                       hits, (uint32_t)n, fixup, pp, counters, perm)
-        if (count_work) {
-            if (cached) PT_LAUNCH(true, true); else PT_LAUNCH(true, false);
-        } else {
-            if (cached) PT_LAUNCH(false, true); else PT_LAUNCH(false, false);
-        }
-#undef PT_LAUNCH
+        launch_persistent(k, st, grid_for(n), cfg, pp, s, rays, hits, (uint32_t)n, fixup, pp, counters, perm);
         if (bracket) (void)hipEventRecord(bracket[1], st);
         return;
     }
@@ -376,11 +391,8 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
     if (s.tlas) {
         if (!exact_order && cfg.persistent_blocks > 0) {
             const PersistentParams pp = persistent_params(cfg, s);
-            const unsigned int lds = persistent_lds_bytes(pp);
-            const unsigned int grid = (unsigned int)std::min<uint64_t>(
-                grid_for(n), persistent_grid((const void *)k_trace_any_two_level_persistent, kBlock, cfg, lds));
-            hipLaunchKernelGGL(k_trace_any_two_level_persistent, dim3(grid), dim3(kBlock), lds, st, s,
-                               rays, occluded, (uint32_t)n, pp);
+            launch_persistent(s.big ? k_trace_any_two_level_persistent<true> : k_trace_any_two_level_persistent<false>,
+                              st, grid_for(n), cfg, pp, s, rays, occluded, (uint32_t)n, pp);
             return;
         }
         hipLaunchKernelGGL(k_trace_any_two_level, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays,
@@ -390,18 +402,11 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
     const bool wide = !exact_order && s.n_tri >= 2;
     if (wide && cfg.persistent_blocks > 0) {
         const PersistentParams pp = persistent_params(cfg, s);
-        const unsigned int lds = persistent_lds_bytes(pp);
-        if (pp.cache_nodes > 0) {
-            const unsigned int grid = (unsigned int)std::min<uint64_t>(
-                grid_for(n), persistent_grid((const void *)k_trace_any_persistent<true>, kBlock, cfg, lds));
-            hipLaunchKernelGGL(k_trace_any_persistent<true>, dim3(grid), dim3(kBlock), lds, st, s, rays,
-                               occluded, (uint32_t)n, pp);
-        } else {
-            const unsigned int grid = (unsigned int)std::min<uint64_t>(
-                grid_for(n), persistent_grid((const void *)k_trace_any_persistent<false>, kBlock, cfg, lds));
-            hipLaunchKernelGGL(k_trace_any_persistent<false>, dim3(grid), dim3(kBlock), lds, st, s, rays,
-                               occluded, (uint32_t)n, pp);
-        }
+        using K = void (*)(DeviceScene, const pt_ray *, int32_t *, uint32_t, PersistentParams);
+        static const K table[4] = {k_trace_any_persistent<false, false>, k_trace_any_persistent<false, true>,
+                                   k_trace_any_persistent<true, false>, k_trace_any_persistent<true, true>};
+        launch_persistent(table[(pp.cache_nodes > 0 ? 2 : 0) | (s.big ? 1 : 0)], st, grid_for(n), cfg, pp, s, rays,
+                          occluded, (uint32_t)n, pp);
         return;
     }
     hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays, occluded, n,

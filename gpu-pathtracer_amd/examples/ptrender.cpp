@@ -5,13 +5,19 @@
 //
 //   ptrender scene.obj|scene.gltf|scene.glb out.ppm|.png|.pfm [--size W H] [--spp N] [--depth D] [--nee] [--gpu-build]
 //            [--eye x y z] [--target x y z] [--fov deg] [--seed S] [--film out.raw]
+//            [--gpus N] [--sharding tiles|samples] [--comm]
 //
 // --film writes the raw film (W*H float4: rgb sums and sample count) for exact comparisons.
+// --gpus N renders one frame on N GPUs of this machine: one context, one host thread and one
+// stream per GPU, the scene replicated, the frame split by 64x64 tiles (bit-identical to one
+// GPU) or by sample ranges, and assembled on GPU 0 over RCCL (pt_comm_create_all,
+// pt_film_gather_tiles / pt_film_reduce).  --comm makes the communicator even for one GPU.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mipt.h"
@@ -36,11 +42,12 @@ int main(int argc, char **argv) {
     if (argc < 3) {
         std::fprintf(stderr, "usage: ptrender scene.obj out.ppm|.png|.pfm [--size W H] [--spp N] [--depth D] "
                              "[--nee] [--gpu-build] [--optimize PASSES] [--instanced] [--eye x y z] [--target x y z] [--fov deg] "
-                             "[--seed S] [--film out.raw]\n");
+                             "[--seed S] [--film out.raw] [--gpus N] [--sharding tiles|samples] [--comm]\n");
         return 2;
     }
     uint32_t W = 512, H = 512, spp = 16, depth = 4, seed = 1;
-    bool nee = false, gpu_build = false, instanced = false;
+    bool nee = false, gpu_build = false, instanced = false, force_comm = false, by_tiles = true;
+    int n_gpus = 1;
     int optimize = 0;         // insertion-based optimisation passes over the tree (host or GPU build)
     double eye[3] = {278, 273, -800}, target[3] = {278, 273, 0}, fov = 39.3;
     const char *film_path = nullptr;
@@ -59,6 +66,14 @@ int main(int argc, char **argv) {
         else if (a == "--gpu-build") gpu_build = true;
         else if (a == "--optimize") { need(1); optimize = std::atoi(argv[++i]); }
         else if (a == "--instanced") instanced = true;
+        else if (a == "--gpus") { need(1); n_gpus = std::atoi(argv[++i]); }
+        else if (a == "--comm") force_comm = true;
+        else if (a == "--sharding") {
+            need(1);
+            const std::string v = argv[++i];
+            if (v != "tiles" && v != "samples") { std::fprintf(stderr, "ptrender: --sharding tiles|samples\n"); return 2; }
+            by_tiles = v == "tiles";
+        }
         else { std::fprintf(stderr, "ptrender: unknown option %s\n", a.c_str()); return 2; }
     }
 
@@ -68,19 +83,23 @@ int main(int argc, char **argv) {
         return scene_path.size() >= n && scene_path.compare(scene_path.size() - n, n, suffix) == 0;
     };
     const bool gltf = ends_with(".glb") || ends_with(".gltf");
-    pt_context *ctx = nullptr;
-    CHECK(pt_context_create(0, &ctx));
+    if (n_gpus < 1 || n_gpus > pt_device_count()) {
+        std::fprintf(stderr, "ptrender: --gpus %d, but %d GPU(s) are visible\n", n_gpus, pt_device_count());
+        return 2;
+    }
+    if (instanced && !gltf) { std::fprintf(stderr, "ptrender: --instanced needs a glTF scene\n"); return 2; }
     const std::string passes = std::to_string(optimize);
-    CHECK(pt_context_set_option(ctx, "build.optimize_passes", passes.c_str()));   // trees built on the GPU
-    pt_scene *scene = nullptr;
+
+    // ---- host side, once: the scene file, and the tree if it is built on the host ------------
     pt_mesh *mesh = nullptr;
+    pt_model *model = nullptr;
+    pt_bvh *bvh = nullptr;
+    std::vector<pt_mesh_desc> descs;
     if (instanced) {
         // the glTF scene as structured: each mesh once, its nodes as instances; every tree is
         // left to the library (meshes on the GPU, top level on the host)
-        if (!gltf) { std::fprintf(stderr, "ptrender: --instanced needs a glTF scene\n"); return 2; }
-        pt_model *model = nullptr;
         CHECK(pt_gltf_load_model(argv[1], &model));
-        std::vector<pt_mesh_desc> descs(pt_model_mesh_count(model));
+        descs.resize(pt_model_mesh_count(model));
         for (uint32_t k = 0; k < descs.size(); ++k) {
             const pt_mesh *m = pt_model_mesh(model, k);
             std::memset(&descs[k], 0, sizeof(pt_mesh_desc));
@@ -92,21 +111,13 @@ int main(int argc, char **argv) {
         }
         std::printf("%s: %u meshes, %u instances, %u materials\n", argv[1], (unsigned)descs.size(),
                     pt_model_instance_count(model), pt_model_material_count(model));
-        CHECK(pt_scene_create_instanced(ctx, descs.data(), (uint32_t)descs.size(), pt_model_instances(model),
-                                        pt_model_instance_count(model), nullptr, 0, PT_LINKS_INT_BITS,
-                                        pt_model_materials(model), pt_model_material_count(model), &scene));
-        pt_model_destroy(model);
     } else {
         if (gltf) CHECK(pt_gltf_load(argv[1], 0, &mesh));   // src/main_granite.cpp:268
         else CHECK(pt_obj_load(argv[1], &mesh));
         const uint32_t n_vtx = pt_mesh_vertex_count(mesh), n_tri = pt_mesh_triangle_count(mesh);
         std::printf("%s: %u vertices, %u triangles, %u materials\n", argv[1], n_vtx, n_tri,
                     pt_mesh_material_count(mesh));
-        if (gpu_build) {
-            CHECK(pt_scene_build(ctx, pt_mesh_vertices(mesh), n_vtx, pt_mesh_indices(mesh), n_tri,
-                                 pt_mesh_materials(mesh), pt_mesh_material_count(mesh),
-                                 pt_mesh_material_ids(mesh), PT_LINKS_INT_BITS, &scene));
-        } else {
+        if (!gpu_build) {
             std::vector<pt_bbox> leaves(n_tri);
             CHECK(pt_mesh_leaf_bounds(pt_mesh_vertices(mesh), n_vtx, pt_mesh_indices(mesh), n_tri, leaves.data()));
             pt_bvh_options opt;
@@ -114,13 +125,7 @@ int main(int argc, char **argv) {
             CHECK(pt_bvh_options_set(&opt, "bvh.builder", "sah"));       // src/main_granite.cpp:176
             CHECK(pt_bvh_options_set(&opt, "mipt.link_encoding", "int"));
             CHECK(pt_bvh_options_set(&opt, "mipt.optimize_passes", passes.c_str()));
-            pt_bvh *bvh = nullptr;
             CHECK(pt_bvh_build(leaves.data(), n_tri, &opt, &bvh));
-            CHECK(pt_scene_create(ctx, pt_bvh_nodes(bvh), pt_bvh_node_count(bvh), pt_bvh_link_encoding(bvh),
-                                  pt_mesh_vertices(mesh), n_vtx, pt_mesh_indices(mesh), n_tri,
-                                  pt_mesh_materials(mesh), pt_mesh_material_count(mesh),
-                                  pt_mesh_material_ids(mesh), &scene));
-            pt_bvh_destroy(bvh);
         }
     }
 
@@ -144,19 +149,85 @@ int main(int argc, char **argv) {
     cam.sy = (float)t;
     cam.mode = PT_CAMERA_PINHOLE;
 
-    pt_film *film = nullptr;
-    CHECK(pt_film_create(ctx, W, H, &film));
-    pt_render_params rp;
-    pt_render_params_default(&rp, W, H);
-    rp.sample_count = spp;
-    rp.max_depth = depth;
-    rp.seed = seed;
-    rp.flags = nee ? PT_RENDER_NEE : PT_RENDER_DEFAULT;
-    pt_render_stats st;
-    CHECK(pt_render(ctx, scene, &cam, &rp, film, &st));
+    // ---- one context per GPU, and their communicator --------------------------------------------
+    struct Gpu {
+        pt_context *ctx = nullptr;
+        pt_comm *comm = nullptr;
+        pt_scene *scene = nullptr;
+        pt_film *film = nullptr;
+        pt_render_stats st{};
+    };
+    std::vector<Gpu> gpus((size_t)n_gpus);
+    for (int g = 0; g < n_gpus; ++g) {
+        CHECK(pt_context_create(g, &gpus[(size_t)g].ctx));
+        CHECK(pt_context_set_option(gpus[(size_t)g].ctx, "build.optimize_passes", passes.c_str()));   // trees built on the GPU
+    }
+    if (n_gpus > 1 || force_comm) {
+        std::vector<pt_context *> ctxs;
+        std::vector<pt_comm *> comms((size_t)n_gpus, nullptr);
+        for (Gpu &g : gpus) ctxs.push_back(g.ctx);
+        CHECK(pt_comm_create_all(ctxs.data(), n_gpus, comms.data()));
+        for (int g = 0; g < n_gpus; ++g) gpus[(size_t)g].comm = comms[(size_t)g];
+    }
+
+    // ---- per GPU, each on its own host thread: upload, render this GPU's share, assemble ----------
+    auto drive = [&](int rank) {
+        Gpu &g = gpus[(size_t)rank];
+        if (instanced) {
+            CHECK(pt_scene_create_instanced(g.ctx, descs.data(), (uint32_t)descs.size(), pt_model_instances(model),
+                                            pt_model_instance_count(model), nullptr, 0, PT_LINKS_INT_BITS,
+                                            pt_model_materials(model), pt_model_material_count(model), &g.scene));
+        } else if (gpu_build) {
+            CHECK(pt_scene_build(g.ctx, pt_mesh_vertices(mesh), pt_mesh_vertex_count(mesh), pt_mesh_indices(mesh),
+                                 pt_mesh_triangle_count(mesh), pt_mesh_materials(mesh), pt_mesh_material_count(mesh),
+                                 pt_mesh_material_ids(mesh), PT_LINKS_INT_BITS, &g.scene));
+        } else {
+            CHECK(pt_scene_create(g.ctx, pt_bvh_nodes(bvh), pt_bvh_node_count(bvh), pt_bvh_link_encoding(bvh),
+                                  pt_mesh_vertices(mesh), pt_mesh_vertex_count(mesh), pt_mesh_indices(mesh),
+                                  pt_mesh_triangle_count(mesh), pt_mesh_materials(mesh),
+                                  pt_mesh_material_count(mesh), pt_mesh_material_ids(mesh), &g.scene));
+        }
+        CHECK(pt_film_create(g.ctx, W, H, &g.film));
+        pt_render_params rp;
+        pt_render_params_default(&rp, W, H);
+        rp.sample_count = spp;
+        rp.max_depth = depth;
+        rp.seed = seed;
+        rp.flags = nee ? PT_RENDER_NEE : PT_RENDER_DEFAULT;
+        if (by_tiles) {                      // tiles t with t % n_gpus == rank, every sample of them
+            rp.tile_size = 64;
+            rp.shard_index = (uint32_t)rank;
+            rp.shard_count = (uint32_t)n_gpus;
+        } else {                             // a contiguous range of the samples of every pixel
+            const uint32_t base = spp / (uint32_t)n_gpus, extra = spp % (uint32_t)n_gpus;
+            rp.sample_begin = (uint32_t)rank * base + ((uint32_t)rank < extra ? (uint32_t)rank : extra);
+            rp.sample_count = base + ((uint32_t)rank < extra ? 1u : 0u);
+        }
+        if (rp.sample_count) CHECK(pt_render(g.ctx, g.scene, &cam, &rp, g.film, &g.st));
+        if (g.comm) {
+            if (by_tiles) CHECK(pt_film_gather_tiles(g.film, g.comm, 64, 0));
+            else CHECK(pt_film_reduce(g.film, g.comm, 0));
+            CHECK(pt_context_synchronize(g.ctx));
+        }
+    };
+    if (n_gpus == 1) {
+        drive(0);
+    } else {
+        std::vector<std::thread> threads;
+        for (int g = 0; g < n_gpus; ++g) threads.emplace_back(drive, g);
+        for (std::thread &th : threads) th.join();
+    }
+    pt_render_stats st{};
+    for (const Gpu &g : gpus) {
+        st.paths += g.st.paths;
+        st.rays_primary += g.st.rays_primary;
+        st.rays_bounce += g.st.rays_bounce;
+        st.rays_shadow += g.st.rays_shadow;
+    }
     std::printf("%llu paths, %llu primary + %llu bounce + %llu shadow rays\n",
                 (unsigned long long)st.paths, (unsigned long long)st.rays_primary,
                 (unsigned long long)st.rays_bounce, (unsigned long long)st.rays_shadow);
+    pt_film *film = gpus[0].film;            // the assembled frame
     // container by file extension: .png, .pfm, anything else is PPM
     const std::string out_path = argv[2];
     auto out_ends_with = [&](const char *ext) {
@@ -175,9 +246,14 @@ int main(int argc, char **argv) {
         }
         std::fclose(f);
     }
-    pt_film_destroy(film);
-    pt_scene_destroy(scene);
-    pt_context_destroy(ctx);
+    for (Gpu &g : gpus) {
+        pt_comm_destroy(g.comm);
+        pt_film_destroy(g.film);
+        pt_scene_destroy(g.scene);
+        pt_context_destroy(g.ctx);
+    }
+    pt_bvh_destroy(bvh);
+    pt_model_destroy(model);
     pt_mesh_destroy(mesh);
     return 0;
 }

@@ -103,6 +103,39 @@ def test_lucy_class_28m_secondary_rays_gpu_built_tree(mipt, oracle, scenes, gpu_
         sc.close()
 
 
+def test_scene_beyond_four_gib_of_records(mipt, oracle, scenes, gpu_ctx):
+    """72 M triangles: 72 M two-child nodes (4.6 GB) and 3.5 GB of triangle records, beyond what
+    32-bit byte offsets reach (2^26 nodes, 89 M records), so the kernels compiled for 64-bit
+    record addresses run; 144 M skip-link nodes with integer links.  Tree built on the GPU; the
+    persistent kernels in both ray orders, the fixed-order kernel and the occlusion query agree,
+    and a sample equals the CPU restatement walking the tree read back from the device."""
+    vtx, idx, _, _ = scenes.displaced_sphere(72_000_000, seed=9)
+    assert idx.shape[0] - 1 > 2 ** 26
+    sc = mipt.Scene(gpu_ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
+    try:
+        rays = scenes.surface_rays(vtx, idx, 1 << 20, seed=11).astype(mipt.ray_dtype)
+        got, st = sc.trace_closest(rays, stats=True)
+        gpu_ctx.set_option("trace.sort_rays", 0)
+        try:
+            plain = sc.trace_closest(rays)
+        finally:
+            gpu_ctx.set_option("trace.sort_rays", -1)
+        assert len(same_hits(got, plain)) == 0
+        assert 0.4 < (got["primid"] >= 0).mean() < 0.95
+        assert got["primid"].max() > 2 ** 26               # triangles whose records lie beyond 4 GiB
+        pick = np.random.default_rng(5).choice(len(rays), 50_000, replace=False)
+        assert len(same_hits(sc.trace_closest(rays[pick], mipt.PT_TRACE_EXACT_ORDER), got[pick])) == 0
+        nodes = sc.read_nodes()
+        assert nodes.shape[0] == 2 * idx.shape[0] - 1
+        want = oracle.closest(nodes, vtx, idx, rays[pick[:20_000]], nthreads=16, int_bits=True)
+        assert len(same_hits(got[pick[:20_000]], want)) == 0
+        occ = sc.trace_any(rays[pick])
+        assert ((occ != 0) == (got["primid"][pick] >= 0)).mean() > 0.999
+        print(f"72M tris: {st.box_tests / len(rays):.1f} box + {st.tri_tests / len(rays):.1f} tri tests per ray")
+    finally:
+        sc.close()
+
+
 def test_cornell_1080p_64spp_depth4_full_size(mipt, oracle, scenes, gpu_ctx):
     vtx, idx, mats, mids = scenes.cornell_box()
     nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))

@@ -294,6 +294,18 @@ def test_cpp_host_program_matches_the_binding(mipt, oracle, scenes, gpu_ctx, tmp
         film.close()
         sc.close()
     assert open(ppm, "rb").read().startswith(b"P6\n96 64\n255\n")
+    # the multi-GPU code path of the program on the one GPU there is: a communicator of one rank
+    # (pt_comm_create_all), the frame "split" by tiles and by sample ranges, assembled over RCCL
+    for sharding in ("tiles", "samples"):
+        out = subprocess.run([exe, obj, ppm, "--size", str(W), str(H), "--spp", "5", "--depth", "4", "--nee",
+                              "--seed", "9", "--film", raw, "--gpus", "1", "--comm", "--sharding", sharding],
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        np.testing.assert_array_equal(np.fromfile(raw, dtype=np.float32).reshape(H, W, 4).view(np.uint32),
+                                      got.view(np.uint32))
+    out = subprocess.run([exe, obj, ppm, "--size", str(W), str(H), "--spp", "2", "--gpus", "99"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "GPU(s) are visible" in out.stderr
     out = subprocess.run([exe, obj, ppm, "--size", str(W), str(H), "--spp", "2", "--gpu-build"],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
