@@ -195,6 +195,7 @@ def main():
     st = render_step(0, mipt.PT_RENDER_COUNT_WORK)
     rays0 = max(st.rays_primary + st.rays_bounce, 1)  # the counters cover the closest-hit kernel only
     n_box, n_tri = st.box_tests / rays0, st.tri_tests / rays0
+    n_box_lds = st.lds_box_tests / rays0             # of n_box: on nodes served from the LDS copy of the top levels
     bytes_per_ray = 32.0 * n_box + 48.0 * n_tri + 64.0        # reference-layout bytes per ray
     film.clear()
 
@@ -202,7 +203,7 @@ def main():
     # access pattern, from tables sized to each level of the memory hierarchy -----------------
     ceilings = {}
     if rank == 0:
-        scene_bytes = 64 * (idx.shape[0] - 1) + 48 * idx.shape[0]
+        scene_bytes = max(64 * (idx.shape[0] - 1) + 48 * idx.shape[0], 1 << 16)
         for name, size in (("l1_resident_16KB", 16 << 10), ("l2_resident_2MB", 2 << 20),
                            ("scene_sized_%dMB" % max(1, scene_bytes >> 20), scene_bytes),
                            ("hbm_resident_4GB", 4 << 30)):
@@ -250,7 +251,10 @@ def main():
         img = film_t[..., :3] / film_t[..., 3:].clamp(min=1)
         frame_spp = float(film_t[..., 3].mean().item())
         ext_s = max(extend_ms, 1e-9) * 1e-3
-        records = (n_box / 2 + n_tri) * rays                   # 64-byte nodes + 48-byte triangle records
+        # 64-byte nodes + 48-byte triangle records fetched through the vector memory pipeline (the
+        # nodes of the top levels that the workgroups keep in LDS are counted apart)
+        records = ((n_box - n_box_lds) / 2 + n_tri) * rays
+        records_lds = n_box_lds / 2 * rays
         out = {
             "metric": "Mrays/s (primary+bounce%s), Sponza 1080p depth 8" % ("+shadow" if args.nee else ""),
             "value": total_rays / elapsed / 1e6,
@@ -278,6 +282,7 @@ def main():
                                     "64x64 tiles round-robin over ranks, packed tiles sent to rank 0 at the end"),
                        "assembly": assembly, "ranks_in_communicator": comm.size if comm is not None else world},
             "nodes_per_ray": n_box, "tris_per_ray": n_tri, "bytes_per_ray": bytes_per_ray,
+            "nodes_per_ray_from_lds": n_box_lds, "tree_depth": scene.tree_depth(),
             "tie_rays": int(ties), "mean_radiance": float(img.mean().item()),
             "kernel_ms_per_step": {k: v / args.steps for k, v in kernel_ms.items()},
             "kernel_time_share_of_step": sum(kernel_ms.values()) * 1e-3 / elapsed,
@@ -295,6 +300,7 @@ def main():
             "achieved": records / ext_s / 1e9, "peak": peak_rec, "unit": "Grecords/s",
             "frac": records / ext_s / 1e9 / peak_rec,
             "traffic": None,
+            "records_served_from_lds_grecords_s": records_lds / ext_s / 1e9,
             "launches": int(launches), "avg_launch_ms": extend_ms / max(launches, 1),
             "kernel_time_share": extend_ms * 1e-3 / elapsed,
             "gather_ceilings_measured_in_this_run_grecords_s": ceilings,

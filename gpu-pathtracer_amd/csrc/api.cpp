@@ -791,6 +791,7 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
         stats->box_tests = c.box_tests;
         stats->tri_tests = c.tri_tests;
         stats->tie_rays = c.tie_count;
+        stats->lds_box_tests = c.lds_box_tests;
     }
     return PT_OK;
 }

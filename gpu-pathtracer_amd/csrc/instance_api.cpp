@@ -193,7 +193,13 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
         char *d_nodes = (char *)dev_alloc(sizeof(pt_bbox) * (size_t)tot_nodes);
         char *d_vtx = (char *)dev_alloc(sizeof(float) * 3 * (size_t)tot_vtx);
         char *d_idx = (char *)dev_alloc(sizeof(int32_t) * 3 * (size_t)tot_tri);
-        char *d_wnodes = (char *)dev_alloc(sizeof(WideNode) * (size_t)tot_wnodes);
+        // the two-child nodes of the top level go behind those of the meshes, into the same index
+        // space: the voted loop then steps through both levels with one piece of code
+        const size_t top_room = top_nodes ? (size_t)n_top_nodes : 2 * (size_t)n_instances;
+        if (tot_wnodes + top_room > kMaxWideNodes)
+            return fail(PT_ERR_UNSUPPORTED,
+                        "pt_scene_create_instanced: more nodes than a child index can name");
+        char *d_wnodes = (char *)dev_alloc(sizeof(WideNode) * ((size_t)tot_wnodes + top_room));
         char *d_wtris = (char *)dev_alloc(sizeof(TriRecord) * (size_t)tot_wtris);
         sc->mesh_node_off.resize(n_meshes);
         sc->mesh_node_count.resize(n_meshes);
@@ -419,12 +425,20 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
         d.n_materials = (uint32_t)mats.size();
         d.link_enc = link_encoding;
         d.wide_depth = wide_depth;
-        d.big = needs_big_addresses(tot_wnodes, tot_wtris) ? 1u : 0u;
+        d.big = needs_big_addresses(tot_wnodes + top_room, tot_wtris) ? 1u : 0u;
         d.tlas = (const float4 *)upload(top_nodes, sizeof(pt_bbox) * (size_t)n_top_nodes);
         {
             std::vector<WideNode> wtop;
             build_wide_top(top, wtop);
-            d.wtop = (const float4 *)upload(wtop.data(), sizeof(WideNode) * wtop.size());
+            if (wtop.size() > top_room)
+                return fail(PT_ERR_INVALID, "pt_scene_create_instanced: top-level tree larger than its node array");
+            for (WideNode &w : wtop)
+                for (int c = 0; c < 2; ++c)
+                    if (w.child[c] >= 0) w.child[c] += (int32_t)tot_wnodes;     // a leaf stays ~instance
+            char *dst = d_wnodes + sizeof(WideNode) * (size_t)tot_wnodes;
+            copy_in(dst, wtop.data(), sizeof(WideNode) * wtop.size());
+            d.wtop = (const float4 *)dst;
+            d.top_root = (uint32_t)tot_wnodes;
         }
         d.instances = (const DeviceInstance *)upload(dinst.data(), sizeof(DeviceInstance) * dinst.size());
         d.n_tlas_nodes = n_top_nodes;

@@ -57,7 +57,10 @@ struct DeviceScene {
     // arrays above then hold every mesh back to back, in object space, except stris, which
     // holds one world-space record per instanced triangle.
     const float4 *tlas;
-    const float4 *wtop;    // the same top-level tree as two-child nodes; leaf child = ~instance
+    // the same top-level tree as two-child nodes, stored behind the meshes' nodes in wnodes (its
+    // root is wnodes[top_root], inner children are indices into wnodes); leaf child = ~instance
+    const float4 *wtop;
+    uint32_t top_root;
     const DeviceInstance *instances;
     uint32_t n_tlas_nodes, n_instances;
 };
@@ -91,6 +94,7 @@ struct DeviceTraceCounters {
     unsigned long long tri_tests;
     unsigned int tie_count;   // entries appended to the tie list
     unsigned int _pad;
+    unsigned long long lds_box_tests;   // of box_tests: on nodes read from the LDS copy of the top of the tree
 };
 
 // How the closest-hit kernels are launched.

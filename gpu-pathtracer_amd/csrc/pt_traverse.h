@@ -362,7 +362,8 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                                                 int32_t *stack, int min_active, int leaf_lanes,
                                                 unsigned long long &nb, unsigned long long &nt,
                                                 int stack_cap = kTraceStack,
-                                                const float4 *cache = nullptr) {
+                                                const float4 *cache = nullptr,
+                                                unsigned long long *nl = nullptr) {
     for (;;) {
         // Node steps run in a loop of their own: only the position and the stack pointer
         // change in it, so the rest of the lane's state stays put in its registers.
@@ -384,6 +385,7 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                     const float4 *np = cache + ((st.cur - kLdsNodeBase) << 2);
                     a = np[0]; b = np[1]; c = np[2];
                     ch = reinterpret_cast<const int4 *>(np)[3];
+                    if (COUNT && nl) *nl += 2;
                 } else {
                     const float4 *np = wide_node<BIG>(s, st.cur);
                     a = np[0]; b = np[1]; c = np[2];
@@ -830,7 +832,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     st.primid = -1;
     st.second = INFINITY;
     st.tbest = 0.f;
-    unsigned long long nb = 0, nt = 0;
+    unsigned long long nb = 0, nt = 0, nl = 0;  // slab tests, triangle tests, slab tests on LDS nodes
     unsigned int n_ties = 0;
     const bool any_exact = s.n_tri < 2;         // see occluded_wide
     int spilled = 0;                            // blocks of this lane's stack in global memory
@@ -940,37 +942,84 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
             continue;                                           // tail positions past the queue end
         }
         ordered_advance<COUNT, ANY, CACHE, BIG>(s, st, stack, pos < stream_len ? 64 - refill : 0,
-                                                leaf_lanes, nb, nt, stack_cap, cache);
+                                                leaf_lanes, nb, nt, stack_cap, cache, &nl);
     }
     if constexpr (!ANY) walk_parked();
     if (!ANY && n_ties) atomicAdd(tie_count, n_ties);
     if (COUNT) {
         nb = wave_sum(nb);
         nt = wave_sum(nt);
+        nl = wave_sum(nl);
         if (lane == 0) {
             atomicAdd(&work->box_tests, nb);
             atomicAdd(&work->tri_tests, nt);
+            atomicAdd(&work->lds_box_tests, nl);
         }
     }
 }
 
-// The same persistent loop for two-level scenes.  A lane owns one ray; each instance it
-// reaches is one run of the voted state machine above on the object-space ray.  Lanes whose
-// run has ended are serviced together -- result merged, top-level walk resumed up to the next
-// instance or the end of the ray, idle lanes refilled -- once `refill` of them have gathered
-// (fewer when few lanes are busy), so the voted steps keep most lanes.
+// ---- the persistent loop for two-level scenes ------------------------------------------------
+// One voted loop over both levels.  A lane is either in world space, walking the top-level
+// tree's two-child nodes (from s.top_root on; a negative child is the complement of an instance
+// index), or
+// inside an instance, walking that mesh's nodes and triangle records with the ray taken to the
+// instance's object space.  The top level's nodes lie in the same array as the meshes', so a
+// node step is the same code on either level.  Besides the node step and the triangle step there is a third kind of
+// step, voted like the other two: entering an instance (transform the ray, put an exit mark on
+// the stack, go to the mesh's root) and leaving one (the exit mark has been popped: back to the
+// world-space ray).  Everything below the mark on a lane's stack belongs to the top level,
+// everything above it to the mesh, so one stack serves both.
 //
-// The top level is walked nearer child first over its own two-child nodes (s.wtop; a leaf
-// child is the complement of an instance index), on the bottom entries of the lane's stack;
-// the mesh search runs above them.  The argument that makes the ordered single-level
-// traversal return the fixed-order result carries over one level up: every mesh is searched
-// with the culling distance (nearest hit widened by the tie window), so a second candidate --
-// in another instance or in the same mesh -- within the window of the nearest one is seen,
-// and such a ray (also one that is non-finite or overflows the stack) is traced again by its
-// lane with closest_hit_two_level, i.e. in the fixed order of both levels.
-//
-// Every service moves a lane's top-level walk forward or retires its ray, and every wave's
-// stream is finite: the grid drains.
+// Why this returns the fixed-order result of both levels: as one level down.  The ray parameter
+// is the same in both spaces, every box (top-level or mesh) is culled with the nearest hit
+// widened by the tie window, so any second candidate within the window of the nearest -- in the
+// same mesh or in another instance -- is seen, and such a ray (also a non-finite one, or one
+// that outgrows stack and spill slots) is traced again by its lane in the fixed order of both
+// levels (closest_hit_two_level / occluded_two_level with exact = true, which need no stack).
+constexpr int32_t kExitMark = INT_MIN + 1;
+
+struct InstanceRay {
+    float4 o, d;          // the ray in the instance's object space
+    int32_t root;         // first two-child node of the instance's mesh
+    uint32_t n_tri;
+};
+__device__ __forceinline__ InstanceRay instance_ray(const DeviceScene &s, int32_t instance,
+                                                    const float4 ro, const float4 rd) {
+    const float4 *ip = reinterpret_cast<const float4 *>(s.instances + instance);
+    const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+    const uint4 o0 = reinterpret_cast<const uint4 *>(ip)[3];
+    const uint4 o1 = reinterpret_cast<const uint4 *>(ip)[4];
+    InstanceRay x;
+    x.root = (int32_t)o0.y;
+    x.n_tri = o1.y;
+    x.o.x = ((r0.x * ro.x + r0.y * ro.y) + r0.z * ro.z) + r0.w;      // as enter_instance
+    x.o.y = ((r1.x * ro.x + r1.y * ro.y) + r1.z * ro.z) + r1.w;
+    x.o.z = ((r2.x * ro.x + r2.y * ro.y) + r2.z * ro.z) + r2.w;
+    x.o.w = ro.w;
+    x.d.x = (r0.x * rd.x + r0.y * rd.y) + r0.z * rd.z;
+    x.d.y = (r1.x * rd.x + r1.y * rd.y) + r1.z * rd.z;
+    x.d.z = (r2.x * rd.x + r2.y * rd.y) + r2.z * rd.z;
+    x.d.w = rd.w;
+    return x;
+}
+
+// The per-space part of a lane's state: what the slab and triangle tests read of the ray.
+template <bool ANY>
+__device__ __forceinline__ void set_space_ray(OrderedState &st, const float4 ro, const float4 rd) {
+    if (ANY) {                      // as any_begin: 1/d, and the direction in the shear slots
+        st.r.ox = ro.x; st.r.oy = ro.y; st.r.oz = ro.z;
+        st.r.ix = 1.0f / rd.x; st.r.iy = 1.0f / rd.y; st.r.iz = 1.0f / rd.z;
+        st.r.sx = rd.x; st.r.sy = rd.y; st.r.sz = rd.z;
+        st.r.axis = 2;
+    } else {
+        st.r = precompute_ray(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+    }
+}
+__device__ __forceinline__ bool ray_is_ordinary(const float4 ro, const float4 rd) {
+    const float chk = ((ro.x + ro.y) + (ro.z + rd.x)) + (rd.y + rd.z);
+    return (fabsf(chk) < INFINITY) && (ro.w == ro.w) && !(rd.x == 0.f && rd.y == 0.f && rd.z == 0.f);
+}
+
 template <bool COUNT, bool ANY, bool BIG, class Sink>
 __device__ __forceinline__ void persistent_traverse_two_level(
     const DeviceScene &s, const pt_ray *rays, uint32_t n, bool fixup, const PersistentParams pp,
@@ -989,7 +1038,6 @@ __device__ __forceinline__ void persistent_traverse_two_level(
     const uint32_t stream_len = owned << 6;
     uint32_t pos = 0;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
-    const int kTopStack = stack_cap / 2;         // entries the top-level walk may hold
     uint32_t my_ray = kNone;
     OrderedState st;
     st.cur = kSentinel;
@@ -998,123 +1046,36 @@ __device__ __forceinline__ void persistent_traverse_two_level(
     st.second = INFINITY;
     st.tbest = 0.f;
     st.tmax = 0.f;
-    int32_t top_cur = kSentinel;   // top-level item to visit next (kSentinel: pop one)
-    int top_sp = 0;                // top-level entries on the stack
-    int32_t cur_inst = -1;         // instance whose mesh is being searched
-    bool ray_tie = false;          // leave this ray to the fixed-order walk
-    int32_t best_shape = -1, best_prim = -1;
-    float best_b0 = 0.f, best_b1 = 0.f, best_b2 = 0.f, best_t = 0.f;
-    float second = INFINITY, bound = 0.f;
+    st.sp = 0;
+    int32_t cur_inst = -1;         // instance the lane is inside (-1: world space)
+    int32_t best_shape = -1;       // instance of the nearest hit so far
     unsigned long long nb = 0, nt = 0;
     unsigned int n_ties = 0;
-    int spilled = 0;               // blocks of the mesh search's stack in global memory
+    int spilled = 0;
     for (;;) {
-        if (my_ray != kNone && st.cur == kSentinel &&
-            !(cur_inst >= 0 && stack_service<ANY>(st, stack, spill, top_sp, spilled))) {
+        const bool finished = my_ray != kNone && st.cur == kSentinel &&
+                              !stack_service<ANY>(st, stack, spill, 0, spilled);
+        if (finished) {                                         // retire a finished ray
             const float4 ro = reinterpret_cast<const float4 *>(rays + my_ray)[0];
             const float4 rd = reinterpret_cast<const float4 *>(rays + my_ray)[1];
-            bool done = false;
-            if (cur_inst >= 0) {                                // merge the finished mesh search
-                if constexpr (ANY) {
-                    bool occ = st.primid >= 0;
-                    if (st.tie) {
-                        float4 oo = ro, od = rd;
-                        int32_t root;
-                        const DeviceScene m = enter_instance(s, cur_inst, oo, od, root);
-                        occ = occluded_skiplink(m, oo, od);
-                    }
-                    done = occ;
-                    best_prim = occ ? 0 : -1;
-                } else {
-                    ray_tie |= ordered_is_tie(st);
-                    const int32_t pid = st.primid;
-                    const float ct = st.tbest;
-                    if (pid >= 0) {
-                        if (best_prim < 0 || ct < best_t) {
-                            if (best_prim >= 0) second = fminf(second, best_t);
-                            best_shape = cur_inst; best_prim = pid;
-                            best_b0 = st.b0; best_b1 = st.b1; best_b2 = st.b2; best_t = ct;
-                            bound = ct + ct * PT_TIE_WINDOW;
-                        } else if (cur_inst != best_shape || pid != best_prim) {
-                            second = fminf(second, ct);
-                        }   // else: the same instance reached through another top-level leaf
+            if constexpr (ANY) {
+                bool occ = st.primid >= 0;
+                if (st.tie) occ = occluded_two_level(s, ro, rd, stack, true);
+                sink(my_ray, occ);
+            } else {
+                int32_t shape = st.primid >= 0 ? best_shape : -1, prim = st.primid;
+                float b0 = st.b0, b1 = st.b1, b2 = st.b2, t = st.tbest;
+                if (ordered_is_tie(st)) {
+                    ++n_ties;
+                    if (fixup) {
+                        unsigned long long xb = 0, xt = 0;
+                        closest_hit_two_level<false>(s, ro, rd, stack, true, true, shape, prim, b0, b1,
+                                                     b2, t, xb, xt);
                     }
                 }
-                cur_inst = -1;
+                sink(my_ray, shape, prim, b0, b1, b2, t);
             }
-            if (!done && !ray_tie) {                            // on to the next instance
-                const RayPre r = top_level_ray(ro, rd);
-                const float lim = ANY ? ro.w : bound;
-                for (;;) {
-                    if (top_cur == kSentinel) {
-                        if (top_sp == 0) break;
-                        --top_sp;
-                        top_cur = stack[top_sp * kTraceBlock];
-                    }
-                    if (top_cur >= 0) {
-                        const float4 *np = reinterpret_cast<const float4 *>(
-                            reinterpret_cast<const char *>(s.wtop) + ((uint32_t)top_cur << 6));
-                        const float4 a = np[0], b = np[1], c = np[2];
-                        const int4 ch = reinterpret_cast<const int4 *>(np)[3];
-                        if (COUNT) nb += 2;
-                        float ta, tb;
-                        const bool ha = intersect_box(r, a.x, a.y, a.z, a.w, c.x, c.y, lim, ta);
-                        const bool hb = intersect_box(r, b.x, b.y, b.z, b.w, c.z, c.w, lim, tb);
-                        if (ha && hb) {
-                            if (top_sp >= kTopStack) {
-                                ray_tie = true;
-                                break;
-                            }
-                            const bool swap = tb < ta;
-                            stack[top_sp * kTraceBlock] = swap ? ch.x : ch.y;
-                            ++top_sp;
-                            top_cur = swap ? ch.y : ch.x;
-                        } else if (ha || hb) {
-                            top_cur = ha ? ch.x : ch.y;
-                        } else {
-                            top_cur = kSentinel;
-                        }
-                    } else {
-                        cur_inst = ~top_cur;
-                        top_cur = kSentinel;
-                        float4 oo = ro, od = rd;
-                        int32_t root;
-                        const DeviceScene m = enter_instance(s, cur_inst, oo, od, root);
-                        spilled = 0;
-                        if constexpr (ANY) {
-                            any_begin(st, oo, od, stack, m.n_tri < 2, root, top_sp);
-                        } else {
-                            oo.w = bound;
-                            ordered_begin(st, oo, od, stack, root, top_sp);
-                        }
-                        break;
-                    }
-                }
-            }
-            if (!done) done = cur_inst < 0;                     // no further instance: the ray ends
-            if (done) {
-                if constexpr (ANY) {
-                    bool occ = best_prim >= 0;
-                    if (ray_tie) occ = occluded_two_level(s, ro, rd, stack, false);
-                    sink(my_ray, occ);
-                } else {
-                    const bool tie = ray_tie || (best_prim >= 0 &&
-                                                 second <= best_t + best_t * PT_TIE_WINDOW);
-                    if (tie) {
-                        ++n_ties;
-                        if (fixup) {
-                            unsigned long long xb = 0, xt = 0;
-                            closest_hit_two_level<false>(s, ro, rd, stack, true, false, best_shape,
-                                                         best_prim, best_b0, best_b1, best_b2,
-                                                         best_t, xb, xt);
-                        }
-                    }
-                    sink(my_ray, best_shape, best_prim, best_b0, best_b1, best_b2, best_t);
-                }
-                my_ray = kNone;
-                st.cur = kSentinel;
-                cur_inst = -1;
-            }
+            my_ray = kNone;
         }
         const bool idle = my_ray == kNone;
         const unsigned long long m = __ballot(idle);
@@ -1126,32 +1087,150 @@ __device__ __forceinline__ void persistent_traverse_two_level(
                     const float4 ro = reinterpret_cast<const float4 *>(rays + idx)[0];
                     const float4 rd = reinterpret_cast<const float4 *>(rays + idx)[1];
                     my_ray = idx;
-                    top_cur = 0;
-                    top_sp = 0;
+                    set_space_ray<ANY>(st, ro, rd);
+                    st.tmax = ro.w;
+                    st.tbest = ro.w;
+                    st.bound = ANY ? ro.w : ro.w + ro.w * PT_TIE_WINDOW;
+                    st.second = INFINITY;
+                    st.b0 = 0.f; st.b1 = 0.f; st.b2 = 0.f;
+                    st.primid = -1;
+                    best_shape = -1;
                     cur_inst = -1;
-                    best_shape = -1; best_prim = -1;
-                    best_b0 = 0.f; best_b1 = 0.f; best_b2 = 0.f;
-                    best_t = ro.w;
-                    bound = ro.w;
-                    second = INFINITY;
-                    st.cur = kSentinel;
-                    // non-finite rays and zero directions: whatever the fixed-order arithmetic
-                    // makes of them (see traverse_ordered)
-                    const float chk = ((ro.x + ro.y) + (ro.z + rd.x)) + (rd.y + rd.z);
-                    ray_tie = !(fabsf(chk) < INFINITY) || !(ro.w == ro.w) ||
-                              (rd.x == 0.f && rd.y == 0.f && rd.z == 0.f);
+                    spilled = 0;
+                    stack[0] = kSentinel;
+                    st.sp = 1;
+                    st.cur = (int32_t)s.top_root;               // the top-level root
+                    st.tie = !ray_is_ordinary(ro, rd);          // whatever the fixed order makes of it
+                    if (st.tie) st.cur = kSentinel;
                 }
             }
             pos += (uint32_t)__popcll(m);
-            continue;                                           // they start their top-level walk above
         }
-        const int active = (int)__popcll(__ballot(st.cur != kSentinel));
-        if (active == 0) {
-            if (__ballot(my_ray != kNone) == 0ull) break;       // stream read and every ray retired
-            continue;                                           // lanes waiting for service only
+        if (__ballot(my_ray != kNone) == 0ull) {
+            if (pos >= stream_len) break;
+            continue;                                           // tail positions past the queue end
         }
-        const int batch = min(refill, max(1, active >> 1));
-        ordered_advance<COUNT, ANY, false, BIG>(s, st, stack, active - batch, leaf_lanes, nb, nt, stack_cap);
+        // ---- voted steps until enough lanes have finished for a refill to pay ----------------
+        const int min_active = pos < stream_len ? 64 - refill : 0;
+        for (;;) {
+            // The vote: 0 node step, 1 triangle step, 2 instance step (enter or leave), 3 enough
+            // lanes are idle.  The same value in every lane.
+            bool at_node, at_tri, at_inst;
+            auto vote = [&]() {
+                const bool in_obj = cur_inst >= 0;
+                at_node = st.cur >= 0;
+                at_tri = in_obj & (st.cur < 0) & (st.cur > kExitMark);
+                at_inst = (st.cur != kSentinel) & !at_node & !at_tri;   // an instance to enter, or the exit mark
+                const int n_node = (int)__popcll(__ballot(at_node));
+                const int n_tri = (int)__popcll(__ballot(at_tri));
+                const int n_inst = (int)__popcll(__ballot(at_inst));
+                if (n_node + n_tri + n_inst <= min_active) return 3;
+                if (n_node != 0 && n_tri < leaf_lanes && n_inst < leaf_lanes) return 0;
+                return (n_inst != 0 && n_inst >= n_tri) ? 2 : 1;
+            };
+            int mode = vote();
+            // node steps in a loop of their own: only position and stack pointer change in it
+            while (mode == 0) {
+                if (at_node) {
+                    const float4 *np = wide_node<BIG>(s, st.cur);
+                    const float4 a = np[0], b = np[1], c = np[2];
+                    const int4 ch = reinterpret_cast<const int4 *>(np)[3];
+                    if (COUNT) nb += 2;
+                    float ta, tb;
+                    const bool ha = intersect_box(st.r, a.x, a.y, a.z, a.w, c.x, c.y, st.bound, ta);
+                    const bool hb = intersect_box(st.r, b.x, b.y, b.z, b.w, c.z, c.w, st.bound, tb);
+                    const bool take_b = hb & (!ha | (tb < ta));
+                    const bool both = ha & hb, none = !(ha | hb);
+                    const bool full = both & (st.sp >= stack_cap);   // see ordered_advance
+                    int32_t next = take_b ? ch.y : ch.x;
+                    const int32_t far_c = take_b ? ch.x : ch.y;
+                    if (both) stack[st.sp * kTraceBlock] = full ? st.cur : far_c;
+                    st.sp += both ? 1 : 0;
+                    if (none) {
+                        --st.sp;
+                        next = stack[st.sp * kTraceBlock];
+                    }
+                    st.cur = full ? kSentinel : next;
+                }
+                mode = vote();
+            }
+            if (mode == 3) break;
+            if (mode == 2) {
+                if (at_inst) {
+                    const float4 ro = reinterpret_cast<const float4 *>(rays + my_ray)[0];
+                    const float4 rd = reinterpret_cast<const float4 *>(rays + my_ray)[1];
+                    if (st.cur == kExitMark) {                  // leave the instance
+                        cur_inst = -1;
+                        set_space_ray<ANY>(st, ro, rd);
+                        --st.sp;
+                        st.cur = stack[st.sp * kTraceBlock];
+                    } else if (st.sp >= stack_cap) {            // no room for the exit mark: as a full node step
+                        stack[st.sp * kTraceBlock] = st.cur;
+                        ++st.sp;
+                        st.cur = kSentinel;
+                    } else {                                    // enter the instance ~cur
+                        const int32_t inst = ~st.cur;
+                        const InstanceRay x = instance_ray(s, inst, ro, rd);
+                        stack[st.sp * kTraceBlock] = kExitMark;
+                        ++st.sp;
+                        cur_inst = inst;
+                        set_space_ray<ANY>(st, x.o, x.d);
+                        st.cur = x.root;
+                        // an object-space ray that is not finite, and (occlusion only) a mesh of a
+                        // single triangle, whose filler record is safe under the watertight test
+                        // alone: left to the fixed order
+                        if (!ray_is_ordinary(x.o, x.d) || (ANY && x.n_tri < 2)) {
+                            st.tie = true;
+                            st.cur = kSentinel;
+                        }
+                    }
+                }
+            } else if (at_tri) {                                // triangle step, inside an instance
+                const float4 *tp = wide_tri<BIG>(s, st.cur);
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                if (COUNT) ++nt;
+                if constexpr (ANY) {
+                    float m1, m2, temp;
+                    moller_trumbore(st.r.ox, st.r.oy, st.r.oz, st.r.sx, st.r.sy, st.r.sz, q0.x, q0.y,
+                                    q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, m1, m2, temp);
+                    const bool hit = !((m1 < -PT_MT_EPS) | (m1 > 1.f + PT_MT_EPS) | (m2 < -PT_MT_EPS) |
+                                       (m1 + m2 > 1.f + PT_MT_EPS) | (temp < -PT_MT_EPS) |
+                                       (temp > st.tmax + PT_MT_EPS));           // bvh.glslh:301
+                    st.primid = hit ? 0 : st.primid;
+                    --st.sp;
+                    const int32_t popped = stack[st.sp * kTraceBlock];
+                    st.cur = hit ? kSentinel : popped;
+                } else {
+                    float h0 = 0.f, h1 = 0.f, h2 = 0.f, ht = 0.f;
+                    const bool hit = intersect_triangle_watertight(st.r, q0.x, q0.y, q0.z, q0.w, q1.x,
+                                                                   q1.y, q1.z, q1.w, q2.x, st.bound, h0,
+                                                                   h1, h2, ht);
+                    const int32_t tri = __float_as_int(q2.y);
+                    const bool bad = hit & !(ht == ht);
+                    const bool had = st.primid >= 0;
+                    const bool closer = hit & !bad & (!had | (ht < st.tbest));
+                    // the triangle already held, met again (another leaf of it in a tree built with
+                    // spatial splits, or its instance reached through another top-level leaf), is no
+                    // competing candidate
+                    const bool same = (tri == st.primid) & (cur_inst == best_shape);
+                    const bool farther = hit & !bad & !closer & !same;
+                    const float s_old = fminf(st.second, st.tbest), s_new = fminf(st.second, ht);
+                    st.second = (closer & had) ? s_old : (farther ? s_new : st.second);
+                    st.tbest = closer ? ht : st.tbest;
+                    st.b0 = closer ? h0 : st.b0;
+                    st.b1 = closer ? h1 : st.b1;
+                    st.b2 = closer ? h2 : st.b2;
+                    st.primid = closer ? tri : st.primid;
+                    best_shape = closer ? cur_inst : best_shape;
+                    const float nbound = ht + ht * PT_TIE_WINDOW;   // see ordered_advance
+                    st.bound = closer ? nbound : st.bound;
+                    st.tie |= bad | (hit & !bad & (nbound >= st.tmax));
+                    --st.sp;
+                    const int32_t popped = stack[st.sp * kTraceBlock];
+                    st.cur = bad ? kSentinel : popped;
+                }
+            }
+        }
     }
     if (!ANY && n_ties) atomicAdd(tie_count, n_ties);
     if (COUNT) {

@@ -344,6 +344,7 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
             HIP_CHECK(hipMemcpy(&wc, work, sizeof(wc), hipMemcpyDeviceToHost));
             stats->box_tests = wc.box_tests;
             stats->tri_tests = wc.tri_tests;
+            stats->lds_box_tests = wc.lds_box_tests;
         }
         stats->extend_launches = (uint64_t)n_pass * p.max_depth;
         if (timing) {

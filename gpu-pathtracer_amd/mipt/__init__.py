@@ -71,7 +71,7 @@ class RenderParams(C.Structure):
 
 class TraceStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("tie_rays", C.c_uint64)]
+                ("tie_rays", C.c_uint64), ("lds_box_tests", C.c_uint64)]
 
 
 class RenderStats(C.Structure):
@@ -80,7 +80,7 @@ class RenderStats(C.Structure):
                 ("extend_launches", C.c_uint64), ("extend_ms", C.c_double),
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("raygen_ms", C.c_double), ("shade_ms", C.c_double), ("occlude_ms", C.c_double),
-                ("accumulate_ms", C.c_double)]
+                ("accumulate_ms", C.c_double), ("lds_box_tests", C.c_uint64)]
 
 
 class MeshDesc(C.Structure):

@@ -86,6 +86,7 @@ typedef struct pt_trace_stats {
     uint64_t box_tests;         /* AABB slab tests */
     uint64_t tri_tests;         /* ray/triangle tests */
     uint64_t tie_rays;          /* rays re-resolved in skip-link order */
+    uint64_t lds_box_tests;     /* of box_tests: on nodes served from the LDS copy of the top of the tree */
 } pt_trace_stats;
 
 /* Counters of one pt_render call. */
@@ -103,6 +104,7 @@ typedef struct pt_render_stats {
     double   shade_ms;          /* by kind */
     double   occlude_ms;
     double   accumulate_ms;
+    uint64_t lds_box_tests;     /* with PT_RENDER_COUNT_WORK: slab tests on nodes served from LDS */
 } pt_render_stats;
 
 /* ------------------------------------------------------------------------ */

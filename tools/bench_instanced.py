@@ -38,7 +38,7 @@ t0 = time.perf_counter()
 two = mipt.Scene.instanced(ctx, meshes, tr, mesh_of, top)
 t_two = time.perf_counter() - t0
 
-W, H = 1920, 1080
+W, H = (int(os.environ.get("BENCH_W", 1920)), int(os.environ.get("BENCH_H", 1080)))
 span = n_side * 2.6 * ext
 cam = mipt.look_at_camera((span * 0.5, span * 0.35, -span * 0.25), (span * 0.5, 0.0, span * 0.45),
                           fovy_deg=50.0, aspect=W / H)
@@ -61,6 +61,11 @@ out = {"instances": n_side * n_side, "mesh_triangles": mesh_tris,
        "instanced_triangles": n_side * n_side * mesh_tris, "mesh_build_s": round(t_mesh, 2),
        "two_level_create_s": round(t_two, 2)}
 out["two_level_primary_mrays_s"] = rate(two, d_r)
+stp = two.trace_closest_device_counted(d_r.data_ptr(), n, d_h.data_ptr())
+out["primary_boxes_per_ray"] = stp.box_tests / n
+out["primary_triangles_per_ray"] = stp.tri_tests / n
+out["primary_gbox_tests_s"] = out["two_level_primary_mrays_s"] * out["primary_boxes_per_ray"] / 1e3
+two.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr()); ctx.synchronize()
 hits = d_h.cpu().numpy().view(mipt.hit_dtype).reshape(-1)
 out["primary_hit_fraction"] = float((hits["primid"] >= 0).mean())
 # bounce rays: from the hit points, cosine-ish directions about +y jittered (scene is a field)
