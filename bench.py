@@ -323,9 +323,9 @@ def main():
             if same:
                 gb = tr["traffic_bytes_per_launch"] / 1e9
                 out["roofline"]["traffic"] = gb
-                out["roofline"]["traffic_source"] = ("copied from profiles/r02_traffic.json (rocprofv3 --pmc "
-                                                     "passes over this command: 2 x FETCH_SIZE + WRITE_SIZE), "
-                                                     "not measured by this run")
+                out["roofline"]["traffic_source"] = ("GB per launch, copied from profiles/r02_traffic.json (rocprofv3 "
+                                                     "--pmc passes over this command; FETCH_SIZE calibrated there "
+                                                     "on 64-byte gathers of known size), not measured by this run")
                 out["roofline"]["hbm_frac_from_traffic"] = gb / (extend_ms / max(launches, 1) * 1e-3) / HBM_PEAK_GBS
                 if "counters" in tr:
                     out["roofline"]["counters_copied_from_profiles"] = tr["counters"]
@@ -407,7 +407,8 @@ def hbm_record(args, ctx, torch, mipt, scenes):
         with open(tpath) as f:
             tr = json.load(f)
         rec["traffic"] = tr["traffic_bytes_per_launch"] / 1e9
-        rec["traffic_source"] = "copied from profiles/r02_traffic_hbm.json (rocprofv3 --pmc passes), not measured by this run"
+        rec["traffic_source"] = ("GB per launch, copied from profiles/r02_traffic_hbm.json (rocprofv3 --pmc passes; "
+                                 "FETCH_SIZE calibrated there on 64-byte gathers of known size), not measured by this run")
         rec["hbm_frac_from_traffic"] = rec["traffic"] / (best["kernel_ms"] * 1e-3) / HBM_PEAK_GBS
     return rec
 
