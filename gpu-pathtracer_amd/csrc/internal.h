@@ -32,7 +32,7 @@ struct pt_context {
     bool kernel_timing = false;
     int num_cus = 0;
     int extend_persistent = 1;      // option "extend.persistent"
-    int extend_refill = 40;         // option "extend.refill"
+    int extend_refill = 24;         // option "extend.refill"
     int extend_leaf_lanes = 16;     // option "extend.leaf_lanes"
     int extend_blocks_per_cu = -1;  // option "extend.blocks_per_cu" (-1: chosen per scene, 5 or 4)
     int extend_stack_entries = -1;  // option "extend.stack_entries" (-1: chosen per scene)

@@ -46,8 +46,22 @@ extern __shared__ __align__(16) unsigned char g_persistent_lds[];
 __device__ __forceinline__ int32_t *persistent_stack() {      // this lane's column
     return reinterpret_cast<int32_t *>(g_persistent_lds) + threadIdx.x;
 }
-__device__ __forceinline__ float4 *persistent_cache(int stack_cap) {   // behind the stacks
-    return reinterpret_cast<float4 *>(g_persistent_lds + (size_t)(stack_cap + 1) * kTraceBlock * 4);
+// The node copy is read through a pointer that says "LDS" in its type: given a generic pointer the
+// compiler folds the two sources of a node (LDS or global memory) into one flat load, which
+// goes through the vector memory pipeline like the global loads it was meant to replace.
+typedef float NativeFloat4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) NativeFloat4 LdsFloat4;
+__device__ __forceinline__ float4 lds_load4(const LdsFloat4 *p) {
+    const NativeFloat4 v = *p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_store4(LdsFloat4 *p, const float4 v) {
+    NativeFloat4 w;
+    w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    *p = w;
+}
+__device__ __forceinline__ LdsFloat4 *persistent_cache(int stack_cap) {   // behind the stacks
+    return (LdsFloat4 *)(g_persistent_lds + (size_t)(stack_cap + 1) * kTraceBlock * 4);
 }
 
 __device__ __forceinline__ void store_hit(pt_hit *hits, uint64_t i, int32_t shapeid, int32_t primid,
@@ -362,7 +376,7 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                                                 int32_t *stack, int min_active, int leaf_lanes,
                                                 unsigned long long &nb, unsigned long long &nt,
                                                 int stack_cap = kTraceStack,
-                                                const float4 *cache = nullptr,
+                                                const LdsFloat4 *cache = nullptr,
                                                 unsigned long long *nl = nullptr) {
     for (;;) {
         // Node steps run in a loop of their own: only the position and the stack pointer
@@ -382,9 +396,10 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                 float4 a, b, c;
                 int4 ch;
                 if (CACHE && st.cur >= kLdsNodeBase) {      // a node of the top of the tree, in LDS
-                    const float4 *np = cache + ((st.cur - kLdsNodeBase) << 2);
-                    a = np[0]; b = np[1]; c = np[2];
-                    ch = reinterpret_cast<const int4 *>(np)[3];
+                    const LdsFloat4 *np = cache + ((st.cur - kLdsNodeBase) << 2);
+                    a = lds_load4(np); b = lds_load4(np + 1); c = lds_load4(np + 2);
+                    const float4 cw = lds_load4(np + 3);
+                    ch = make_int4(__float_as_int(cw.x), __float_as_int(cw.y), 0, 0);
                     if (COUNT && nl) *nl += 2;
                 } else {
                     const float4 *np = wide_node<BIG>(s, st.cur);
@@ -786,7 +801,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     // The top of the tree goes to LDS once per workgroup, and rays then start at its first node.
     // The scene's array names a child inside it kLdsNodeBase + position; a workgroup that keeps
     // fewer nodes than the array holds gives the children beyond its share their global names.
-    float4 *const cache = CACHE ? persistent_cache(stack_cap) : nullptr;
+    LdsFloat4 *const cache = CACHE ? persistent_cache(stack_cap) : nullptr;
     int32_t root = 0;
     if (CACHE) {
         const uint32_t n_cached = min((uint32_t)pp.cache_nodes, s.n_top_cache);
@@ -799,7 +814,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                 v.x = __int_as_float(c0);
                 v.y = __int_as_float(c1);
             }
-            cache[i] = v;
+            lds_store4(cache + i, v);
         }
         __syncthreads();
         if (n_cached) root = kLdsNodeBase;

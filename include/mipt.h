@@ -200,7 +200,7 @@ int pt_context_set_kernel_timing(pt_context *ctx, int on);
 int pt_context_last_trace_ms(pt_context *ctx, double *ms);
 /* Tuning knobs (integers as strings).  "extend.persistent" 1|0: closest-hit kernel of
  * pt_render as persistent waves that refill idle lanes (default 1) or one thread per ray;
- * "extend.refill" 1..64: idle lanes that trigger a refill (default 40);
+ * "extend.refill" 1..64: idle lanes that trigger a refill (default 24);
  * "extend.leaf_lanes" 1..64: lanes waiting at a triangle that trigger a triangle step of the
  * wave (default 16); "extend.blocks_per_cu" 1..8: persistent workgroups per compute unit
  * (default 5); "extend.stack_entries" -1|9..30 and "extend.cache_nodes" -1|0..448: how a
