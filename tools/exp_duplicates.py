@@ -9,6 +9,9 @@ import mipt
 from mipt import scenes
 
 ctx = mipt.Context(0)
+for o in sys.argv[1:]:
+    k, _, v = o.partition("=")
+    ctx.set_option(k, int(v))
 vtx, idx, _, _ = scenes.atrium(262144, seed=42)
 n = 1 << 22
 rays = scenes.surface_rays(vtx, idx, n, seed=7).astype(mipt.ray_dtype)
