@@ -74,10 +74,12 @@ ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bo
     c.xcd_slots = ctx->extend_xcd_slots > 0 ? 1 : 0;
     // The LDS of a persistent workgroup (measured on MI355X, 262 K-triangle scene in the caches
     // and 28 M-triangle scene beyond them):
-    //  - a tree of moderate depth gets by with 16 stack entries per lane, and 224 cached nodes
-    //    (the top 7-8 levels) take a tenth off the launch;
+    //  - a tree of moderate depth whose records stay in the caches gets by with 16 stack
+    //    entries per lane, and 224 cached nodes (the top 7-8 levels) take a tenth off the launch;
     //  - a deep tree (GPU-built trees over millions of triangles: 50-70 levels) needs its stack,
-    //    or its rays live in the global spill slots: 24 entries + 96 nodes;
+    //    or its rays live in the global spill slots: 24 entries + 96 nodes. So does any tree
+    //    beyond the caches, where a spilled entry costs a memory round trip (36-level host
+    //    tree over 28 M triangles, sorted rays: 13.2 ms with 16 + 224, 12.25 ms with 24 + 96);
     //  - incoherent rays on a scene beyond the Infinity Cache run best with four workgroups per
     //    compute unit instead of five (fewer rays in flight thrash the caches less): the LDS
     //    that frees goes to the full stack and 128 nodes.
@@ -87,7 +89,7 @@ ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bo
     const uint64_t scene_bytes = 64ull * d.n_wnodes + 48ull * d.n_tri;
     const bool beyond_caches = scene_bytes > (256ull << 20);
     int stack = PT_LDS_STACK_ENTRIES, cache = 0;
-    if (shallow) {
+    if (shallow && !beyond_caches) {
         stack = 16; cache = 224;
     } else if (!two_level) {
         if (beyond_caches && !sorted) {

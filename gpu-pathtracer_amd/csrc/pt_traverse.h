@@ -309,6 +309,9 @@ struct OrderedState {
     int32_t primid, cur;     // cur == kSentinel: no traversal in progress
     int sp;
     bool tie;
+    // the tie flag came from a value that is not finite (the ray, or a hit distance): what the
+    // fixed order makes of such a ray is not bounded by any hit found here
+    bool wild;
 };
 
 __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro, const float4 rd,
@@ -321,6 +324,7 @@ __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro,
     st.second = INFINITY;
     st.primid = -1;
     st.tie = false;
+    st.wild = false;
     stack[base * kTraceBlock] = kSentinel;   // bottom of the stack: popping it ends the ray
     st.sp = base + 1;
     st.cur = root;
@@ -328,6 +332,7 @@ __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro,
     if (!(fabsf(chk) < INFINITY) || !(st.tmax == st.tmax) ||
         (rd.x == 0.f && rd.y == 0.f && rd.z == 0.f)) {
         st.tie = true;
+        st.wild = true;
         st.cur = kSentinel;
     }
 }
@@ -350,6 +355,7 @@ __device__ __forceinline__ void any_begin(OrderedState &st, const float4 ro, con
     st.b0 = 0.f; st.b1 = 0.f; st.b2 = 0.f;
     st.primid = -1;                // >= 0 once an occluder has been found
     st.tie = false;
+    st.wild = false;
     stack[base * kTraceBlock] = kSentinel;
     st.sp = base + 1;
     st.cur = root;
@@ -478,6 +484,7 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
             const float nbound = ht + ht * PT_TIE_WINDOW;
             st.bound = closer ? nbound : st.bound;
             st.tie |= bad | (hit & !bad & (nbound >= st.tmax));
+            st.wild |= bad;
             --st.sp;
             const int32_t popped = stack[st.sp * kTraceBlock];
             st.cur = bad ? kSentinel : popped;
@@ -844,6 +851,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     OrderedState st;
     st.cur = kSentinel;
     st.tie = false;
+    st.wild = false;
     st.primid = -1;
     st.second = INFINITY;
     st.tbest = 0.f;
@@ -904,10 +912,11 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                 const bool tie = ordered_is_tie(st);
                 n_ties += tie ? 1u : 0u;
                 if (tie && fixup) {
-                    // a complete search's nearest hit bounds the answer; one cut short by a
-                    // non-finite value or a full stack does not
+                    // Any hit found here bounds the answer -- also the nearest so far of a search cut
+                    // short by a full stack: the shader ends no farther than a triangle it would
+                    // accept -- unless the search was cut short by a value that is not finite.
                     float lim = INFINITY, lim_bound = INFINITY;
-                    if (!st.tie && st.primid >= 0) {
+                    if (!st.wild && st.primid >= 0) {
                         lim_bound = st.tbest + st.tbest * PT_TIE_WINDOW;
                         // The walk must enter every box on the way to that hit.  A box's computed
                         // entry distance can lie past the computed hit distance by rounding (a flat
@@ -1057,6 +1066,7 @@ __device__ __forceinline__ void persistent_traverse_two_level(
     OrderedState st;
     st.cur = kSentinel;
     st.tie = false;
+    st.wild = false;
     st.primid = -1;
     st.second = INFINITY;
     st.tbest = 0.f;
