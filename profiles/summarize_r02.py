@@ -131,7 +131,7 @@ for fname, prefix, label, rays in (
            "traffic_bytes_per_launch_if_every_fetch_were_a_streaming_read": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
            "counters": derived(c)}
     if fname == "r02_traffic.json":
-        rec["workload"] = [262144, 1920, 1080, 8, 16, 0, False, "synthetic"]
+        rec["workload"] = [262144, 1920, 1080, 8, 64, 0, False, "synthetic"]
     json.dump(rec, open(os.path.join(here, fname), "w"), indent=2)
     print(fname, json.dumps(rec["counters"]), "traffic GB/launch", rec["traffic_bytes_per_launch"] / 1e9)
 
