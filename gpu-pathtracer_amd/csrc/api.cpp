@@ -457,6 +457,37 @@ static int attach_top_cache(pt_context *ctx, pt_scene *sc) {
     return PT_OK;
 }
 
+// Each triangle's leaf in the skip-link array, for deciding two-candidate ties at their leaves
+// (replay_candidates).  Left out when a triangle has several leaves (a tree with spatial splits).
+static int attach_tri_leaf(pt_context *ctx, pt_scene *sc) {
+    const DeviceScene &d = sc->dev;
+    if (d.n_tri < 2) return PT_OK;
+    void *buf = nullptr;
+    const size_t bytes = 4 * (size_t)d.n_tri;
+    hipError_t e = hipMalloc(&buf, bytes + 16);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(triangle leaves)");
+    uint32_t *multi_dev = reinterpret_cast<uint32_t *>((char *)buf + bytes);
+    uint32_t multi = 1;
+    e = hipMemsetAsync(buf, 0xFF, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(multi_dev, 0, 16, ctx->stream);
+    if (e == hipSuccess) {
+        launch_build_tri_leaf(ctx->stream, d.nodes, d.n_nodes, d.link_enc, d.n_tri, (int32_t *)buf, multi_dev);
+        e = hipMemcpyAsync(&multi, multi_dev, 4, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(buf);
+        return hip_fail(e, "triangle leaf table");
+    }
+    if (multi) {
+        (void)hipFree(buf);
+        return PT_OK;
+    }
+    sc->allocs.push_back(buf);
+    sc->dev.tri_leaf = (const int32_t *)buf;
+    return PT_OK;
+}
+
 int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
                     uint32_t link_encoding, const float *vtx, uint32_t n_vtx, const int32_t *idx,
                     uint32_t n_tri, const pt_material *materials, uint32_t n_materials,
@@ -573,7 +604,8 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     d.wide_depth = wide.max_depth;
     d.big = needs_big_addresses(wide.nodes.size(), wide.tris.size()) ? 1u : 0u;
     if (n_tri >= 2) {
-        const int rc = attach_top_cache(ctx, sc.get());
+        int rc = attach_top_cache(ctx, sc.get());
+        if (rc == PT_OK) rc = attach_tri_leaf(ctx, sc.get());
         if (rc != PT_OK) return rc;
     }
     *out = sc.release();
@@ -706,7 +738,8 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
     d.wide_depth = br.max_depth;
     d.big = needs_big_addresses(n_tri - 1, n_tri) ? 1u : 0u;
     {
-        const int rc = attach_top_cache(ctx, sc.get());
+        int rc = attach_top_cache(ctx, sc.get());
+        if (rc == PT_OK) rc = attach_tri_leaf(ctx, sc.get());
         if (rc != PT_OK) return rc;
     }
     *out = sc.release();

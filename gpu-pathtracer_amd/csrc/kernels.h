@@ -52,6 +52,10 @@ struct DeviceScene {
     const float4 *top_cache;
     const int32_t *top_global;   // index in wnodes of each node of top_cache
     uint32_t n_top_cache;
+    // Single-level scenes in which every triangle has exactly one leaf: the index in `nodes` of
+    // each triangle's leaf (null otherwise).  Lets a ray with two near-equal candidates be
+    // decided at those two leaves instead of by a walk over the whole tree.
+    const int32_t *tri_leaf;
     // Two-level scenes only (tlas != nullptr): a skip-link tree over the instances whose leaf
     // payload is an instance index (the "top-level BVH" of src/bvh/bvh_builder.h:31); the
     // arrays above then hold every mesh back to back, in object space, except stris, which
@@ -77,6 +81,10 @@ constexpr int kNodeCacheMax = PT_LDS_NODE_CACHE_MAX;
 // number of nodes to *n_out.
 void launch_build_top_cache(hipStream_t st, const float4 *wnodes, uint32_t n_wnodes, float4 *cache,
                             int32_t *global_index, uint32_t *n_out);
+// Fills tri_leaf[0..n_tri) (preset to -1 by the caller) with the index of each triangle's leaf
+// among the n_nodes skip-link nodes; *multi becomes non-zero if some triangle has several.
+void launch_build_tri_leaf(hipStream_t st, const float4 *nodes, uint32_t n_nodes, uint32_t link_enc,
+                           uint32_t n_tri, int32_t *tri_leaf, uint32_t *multi);
 
 // What a persistent traversal kernel is told about its own loop.
 struct PersistentParams {

@@ -171,6 +171,49 @@ __device__ __forceinline__ void traverse_skiplink(const DeviceScene &s, const fl
     }
 }
 
+// IntersectSceneClosest restricted to the leaves of two triangles, pa and pb, taken in the
+// loop's own order (ascending node index).  This is what the whole loop returns for a ray whose
+// only candidates are those two: every other triangle is either rejected by its own test or
+// lies farther than both by more than rounding can reverse, so it neither ends up as the answer
+// nor changes what the two are compared against; and the loop reaches a leaf exactly when the
+// leaf's own box passes the slab test at the current distance (the boxes above it contain it and
+// rounding is monotonic).  Needs s.tri_leaf.
+__device__ __forceinline__ void replay_candidates(const DeviceScene &s, const float4 ro,
+                                                  const float4 rd, int32_t pa, int32_t pb,
+                                                  int32_t &shapeid, int32_t &primid, float &b0,
+                                                  float &b1, float &b2, float &tbest) {
+    const RayPre r = precompute_ray(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+    b0 = 0.f; b1 = 0.f; b2 = 0.f; tbest = ro.w;
+    shapeid = -1; primid = -1;
+    int32_t na = s.tri_leaf[pa], nb = s.tri_leaf[pb];
+    if (nb < na) {
+        const int32_t tp = pa, tn = na;
+        pa = pb; na = nb;
+        pb = tp; nb = tn;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int32_t node = k ? nb : na, tri = k ? pb : pa;
+        const float4 lo = s.nodes[2 * (int64_t)node + 0];
+        const float4 hi = s.nodes[2 * (int64_t)node + 1];
+        const int32_t i0 = s.idx[3 * (int64_t)tri + 0], i1 = s.idx[3 * (int64_t)tri + 1],
+                      i2 = s.idx[3 * (int64_t)tri + 2];
+        const float *p0 = s.vtx + 3 * (int64_t)i0, *p1 = s.vtx + 3 * (int64_t)i1,
+                    *p2 = s.vtx + 3 * (int64_t)i2;
+        const float v0x = p0[0], v0y = p0[1], v0z = p0[2];
+        const float v1x = p1[0], v1y = p1[1], v1z = p1[2];
+        const float v2x = p2[0], v2y = p2[1], v2z = p2[2];
+        float t0, h0, h1, h2, ht;
+        if (intersect_box(r, lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, tbest, t0) &&
+            intersect_triangle_watertight(r, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, tbest,
+                                          h0, h1, h2, ht)) {
+            b0 = h0; b1 = h1; b2 = h2; tbest = ht;
+            primid = tri;
+            shapeid = 0;
+        }
+    }
+}
+
 // Records of the re-laid-out scene.  BIG = false: by 32-bit byte offset from a uniform base (one
 // scalar base + one vector offset per load), for scenes whose arrays stay below 4 GiB (2^26
 // two-child nodes, 89 M triangle records); BIG = true: 64-bit address arithmetic per lane, for
@@ -307,6 +350,9 @@ struct OrderedState {
     RayPre r;
     float tmax, tbest, bound, second, b0, b1, b2;
     int32_t primid, cur;     // cur == kSentinel: no traversal in progress
+    // The other candidates seen within the tie window of the nearest hit: -1 none, >= 0 exactly
+    // one (its triangle id), -2 several.
+    int32_t other;
     int sp;
     bool tie;
     // the tie flag came from a value that is not finite (the ray, or a hit distance): what the
@@ -323,6 +369,7 @@ __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro,
     st.bound = st.tmax + st.tmax * PT_TIE_WINDOW;     // see the triangle step of ordered_advance
     st.second = INFINITY;
     st.primid = -1;
+    st.other = -1;
     st.tie = false;
     st.wild = false;
     stack[base * kTraceBlock] = kSentinel;   // bottom of the stack: popping it ends the ray
@@ -354,6 +401,7 @@ __device__ __forceinline__ void any_begin(OrderedState &st, const float4 ro, con
     st.second = INFINITY;
     st.b0 = 0.f; st.b1 = 0.f; st.b2 = 0.f;
     st.primid = -1;                // >= 0 once an occluder has been found
+    st.other = -1;
     st.tie = false;
     st.wild = false;
     stack[base * kTraceBlock] = kSentinel;
@@ -471,17 +519,23 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
             const bool farther = hit & !bad & !closer & (__float_as_int(q2.y) != st.primid);
             const float s_old = fminf(st.second, st.tbest), s_new = fminf(st.second, ht);
             st.second = (closer & had) ? s_old : (farther ? s_new : st.second);
-            st.tbest = closer ? ht : st.tbest;
-            st.b0 = closer ? h0 : st.b0;
-            st.b1 = closer ? h1 : st.b1;
-            st.b2 = closer ? h2 : st.b2;
-            st.primid = closer ? __float_as_int(q2.y) : st.primid;
             // Hits near the ray's reach: the test compares products, so a distance an ulp beyond
             // the reach can be accepted -- and the shader then culls at that distance, which lets
             // in a triangle it had turned down at the reach itself, or would have, had it come
             // first.  The reach is therefore widened like every culling distance (ordered_begin),
             // and a ray with a hit within the window of its reach is left to the fixed order.
             const float nbound = ht + ht * PT_TIE_WINDOW;
+            // Who else is within the window of the nearest hit: a hit that is not nearer joins;
+            // a nearer one keeps the old nearest (and whoever was with it) if that is within the
+            // new window, and stands alone if not (the others were no nearer than the old one).
+            const int32_t joined = st.other == -1 ? (closer ? st.primid : __float_as_int(q2.y)) : -2;
+            st.other = farther ? joined
+                               : ((closer & had) ? (st.tbest <= nbound ? joined : -1) : st.other);
+            st.tbest = closer ? ht : st.tbest;
+            st.b0 = closer ? h0 : st.b0;
+            st.b1 = closer ? h1 : st.b1;
+            st.b2 = closer ? h2 : st.b2;
+            st.primid = closer ? __float_as_int(q2.y) : st.primid;
             st.bound = closer ? nbound : st.bound;
             st.tie |= bad | (hit & !bad & (nbound >= st.tmax));
             st.wild |= bad;
@@ -853,6 +907,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     st.tie = false;
     st.wild = false;
     st.primid = -1;
+    st.other = -1;
     st.second = INFINITY;
     st.tbest = 0.f;
     unsigned long long nb = 0, nt = 0, nl = 0;  // slab tests, triangle tests, slab tests on LDS nodes
@@ -866,6 +921,9 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     // places taken has a third to park, and at the end of the wave's stream.
     constexpr int kTieBatch = PT_TIE_BATCH;
     uint32_t parked = kNone, parked2 = kNone;   // two places per lane: batches get larger
+    // Top bit of a parked ray index (indices stay below 2^31): the ray has exactly two candidates
+    // and the two floats parked with it hold their triangle ids instead of distances.
+    constexpr uint32_t kReplay = 0x80000000u;
     float parked_limit = INFINITY, parked2_limit = INFINITY;   // see traverse_skiplink
     float parked_bound = INFINITY, parked2_bound = INFINITY;   // the ordered hit, widened by the window
     auto walk_parked = [&]() {
@@ -873,17 +931,29 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
             int32_t shapeid, primid;
             float b0, b1, b2, t;
             unsigned long long xb = 0, xt = 0;
-            const float4 ro = reinterpret_cast<const float4 *>(rays + parked)[0];
-            const float4 rd = reinterpret_cast<const float4 *>(rays + parked)[1];
-            traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt,
-                                            parked_limit);
-            // The bounded walk starts from a hit the ordered traversal has found, so it must come
-            // back with one at most the tie window beyond it.  If it does not, the rounding
-            // margin in its starting distance was too small for this ray after all: the walk is
-            // repeated from the ray's own reach, which is the reference's loop as written.
-            if (parked_limit < INFINITY && (primid < 0 || !(t <= parked_bound)))
-                traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt);
-            if constexpr (!ANY) sink(parked, shapeid, primid, b0, b1, b2, t);
+            const uint32_t ray = parked & ~kReplay;
+            const float4 ro = reinterpret_cast<const float4 *>(rays + ray)[0];
+            const float4 rd = reinterpret_cast<const float4 *>(rays + ray)[1];
+            if (parked & kReplay) {
+                // two candidates (their ids are in the two floats): decided at their two leaves;
+                // should neither be accepted there, the candidates were not what they seemed and
+                // the ray gets the reference's loop as written
+                replay_candidates(s, ro, rd, __float_as_int(parked_limit),
+                                  __float_as_int(parked_bound), shapeid, primid, b0, b1, b2, t);
+                if (primid < 0)
+                    traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt);
+            } else {
+                traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt,
+                                                parked_limit);
+                // The bounded walk starts from a hit the ordered traversal has found, so it must
+                // come back with one at most the tie window beyond it.  If it does not, the
+                // rounding margin in its starting distance was too small for this ray after all:
+                // the walk is repeated from the ray's own reach, which is the reference's loop as
+                // written.
+                if (parked_limit < INFINITY && (primid < 0 || !(t <= parked_bound)))
+                    traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt);
+            }
+            if constexpr (!ANY) sink(ray, shapeid, primid, b0, b1, b2, t);
             parked = parked2;
             parked_limit = parked2_limit;
             parked_bound = parked2_bound;
@@ -916,7 +986,12 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                     // short by a full stack: the shader ends no farther than a triangle it would
                     // accept -- unless the search was cut short by a value that is not finite.
                     float lim = INFINITY, lim_bound = INFINITY;
-                    if (!st.wild && st.primid >= 0) {
+                    uint32_t mark = my_ray;
+                    if (s.tri_leaf && !st.tie && st.primid >= 0 && st.other >= 0) {
+                        mark |= kReplay;
+                        lim = __int_as_float(st.primid);
+                        lim_bound = __int_as_float(st.other);
+                    } else if (!st.wild && st.primid >= 0) {
                         lim_bound = st.tbest + st.tbest * PT_TIE_WINDOW;
                         // The walk must enter every box on the way to that hit.  A box's computed
                         // entry distance can lie past the computed hit distance by rounding (a flat
@@ -930,11 +1005,11 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                         lim = lim_bound + 3.814697265625e-06f * fmaxf(ex, fmaxf(ey, ez));
                     }
                     if (parked == kNone) {
-                        parked = my_ray;
+                        parked = mark;
                         parked_limit = lim;
                         parked_bound = lim_bound;
                     } else {
-                        parked2 = my_ray;
+                        parked2 = mark;
                         parked2_limit = lim;
                         parked2_bound = lim_bound;
                     }
@@ -1068,6 +1143,7 @@ __device__ __forceinline__ void persistent_traverse_two_level(
     st.tie = false;
     st.wild = false;
     st.primid = -1;
+    st.other = -1;
     st.second = INFINITY;
     st.tbest = 0.f;
     st.tmax = 0.f;

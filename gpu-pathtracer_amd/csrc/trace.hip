@@ -253,6 +253,23 @@ void launch_build_top_cache(hipStream_t st, const float4 *wnodes, uint32_t n_wno
                        global_index, n_out, (int)kNodeCacheMax);
 }
 
+namespace {
+__global__ void k_build_tri_leaf(const float4 *nodes, uint32_t n_nodes, uint32_t link_enc,
+                                 uint32_t n_tri, int32_t *tri_leaf, uint32_t *multi) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int32_t payload = decode_link(nodes[2 * (size_t)i].w, link_enc);
+    if (payload < 0 || (uint32_t)payload >= n_tri) return;
+    if (atomicCAS(&tri_leaf[payload], -1, (int32_t)i) != -1) atomicOr(multi, 1u);
+}
+} // namespace
+
+void launch_build_tri_leaf(hipStream_t st, const float4 *nodes, uint32_t n_nodes, uint32_t link_enc,
+                           uint32_t n_tri, int32_t *tri_leaf, uint32_t *multi) {
+    hipLaunchKernelGGL(k_build_tri_leaf, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, nodes,
+                       n_nodes, link_enc, n_tri, tri_leaf, multi);
+}
+
 unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg,
                              unsigned int lds_bytes) {
     // Never launch more persistent workgroups than can be resident at once: the surplus would

@@ -146,6 +146,18 @@ void tree_from_skip_links(const pt_bbox *nodes, uint32_t n_nodes, uint32_t enc, 
     }
     if (leaves != out.n_prims)
         throw std::runtime_error("skip-link array: leaf count does not match node count");
+    // A child's box must lie within its parent's.  The ordered traversal visits another set of
+    // nodes than the fixed-order loop and returns the same hit only because a leaf whose own box
+    // passes the slab test is reached in either order, which takes boxes that nest.
+    for (uint32_t p = 0; p < n_nodes; ++p) {
+        if (out.right[p] < 0) continue;
+        for (const uint32_t c : {p + 1, (uint32_t)out.right[p]})
+            for (int k = 0; k < 3; ++k)
+                if (nodes[c].pmin[k] < nodes[p].pmin[k] || nodes[c].pmax[k] > nodes[p].pmax[k])
+                    throw std::runtime_error("skip-link array: the box of node " + std::to_string(c) +
+                                             " is not inside the box of its parent, node " +
+                                             std::to_string(p));
+    }
 }
 
 void build_wide_layout(const BvhTree &t, const float *vtx, uint32_t n_vtx, const int32_t *idx,

@@ -71,7 +71,7 @@ def test_device_build_soup(mipt, oracle, scenes, gpu_ctx, enc):
 def test_device_build_is_deterministic_and_handles_duplicates(mipt, oracle, scenes, gpu_ctx):
     """Coincident triangles share one Morton code: ties are broken by position, every run alike."""
     vtx, idx, _, _ = scenes.random_soup(2000, seed=2)
-    idx = np.concatenate([idx, idx[:500], idx[:500]])          # exact duplicates
+    idx = np.concatenate([idx, idx[:500], idx[:500], idx[500:1200]])   # exact duplicates: three and two alike
     a = mipt.Scene(gpu_ctx, None, vtx, idx)
     b = mipt.Scene(gpu_ctx, None, vtx, idx)
     try:

@@ -222,6 +222,37 @@ def test_many_exact_ties_from_duplicated_triangles(mipt, oracle, scenes, gpu_ctx
     assert dup.sum() > 1000 or (got["primid"] < 2000).sum() > 1000
 
 
+def test_pairs_of_near_coincident_triangles(mipt, oracle, scenes, gpu_ctx):
+    """Two candidates within the tie window are decided at their two leaves, without a walk over
+    the tree: exact copies, copies with the vertices rotated (another rounding of the same
+    plane), copies moved by a few units in the last place, and copies moved far enough to be
+    outside the window for some rays and inside for others."""
+    vtx, idx, _, _ = scenes.random_soup(4000, seed=29)
+    n = idx.shape[0]
+    moved = vtx.copy()
+    moved[:, 2] = np.nextafter(np.nextafter(moved[:, 2], np.float32(np.inf)), np.float32(np.inf))
+    far = vtx.copy()
+    far[:, 2] *= np.float32(1 + 3e-6)
+    v = np.concatenate([vtx, moved, far])
+    nv = vtx.shape[0]
+    idx = np.concatenate([idx, idx[:800], idx[800:1600][:, [1, 2, 0]], idx[1600:2400] + nv,
+                          idx[2400:3200] + 2 * nv]).astype(np.int32)
+    for builder in ("sah", "median"):
+        nodes = _build(mipt, v, idx, builder)
+        rays = random_rays(150000, 31, dtype=mipt.ray_dtype)
+        rays["o"][::5, 3] = 2.5
+        got, st = _check_all_modes(mipt, oracle, gpu_ctx, nodes, v, idx, rays,
+                                   expect_ties=lambda t: t > 3000)
+        assert (got["primid"] >= n).sum() > 500 and ((got["primid"] >= 0) & (got["primid"] < 3200)).sum() > 500
+    # the same through the tree built on the GPU (its own table of leaves)
+    sc = mipt.Scene(gpu_ctx, None, v, idx)
+    try:
+        want = oracle.closest(sc.read_nodes(), v, idx, rays, nthreads=8)
+        assert len(same_hits(sc.trace_closest(rays), want)) == 0
+    finally:
+        sc.close()
+
+
 def _comb_tree(oracle, vtx, idx):
     """A hand-made skip-link tree of depth n: inner node i holds triangle i and inner node i+1
     (pre-order: inner_0, leaf_0, inner_1, leaf_1, ..., leaf_{n-2}, leaf_{n-1}; float links)."""

@@ -141,6 +141,12 @@ def test_validate_rejects_broken_arrays(mipt, scenes):
             mipt.validate_bvh(broken, 50)
     with pytest.raises(mipt.MiptError):
         mipt.validate_bvh(nodes[:-1], 50)
+    # a child's box that sticks out of its parent's: the ordered traversal and the fixed-order
+    # loop would no longer agree on which leaves a ray reaches
+    broken = nodes.copy()
+    broken["pmax"][1, 0] = nodes["pmax"][0, 0] + 1.0
+    with pytest.raises(mipt.MiptError, match="not inside the box of its parent"):
+        mipt.validate_bvh(broken, 50)
 
 
 def test_int_bits_link_encoding(mipt, scenes):
