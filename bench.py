@@ -306,6 +306,10 @@ def main():
             "launches": int(launches), "avg_launch_ms": extend_ms / max(launches, 1),
             "kernel_time_share": extend_ms * 1e-3 / elapsed,
             "gather_ceilings_measured_in_this_run_grecords_s": ceilings,
+            # uniform random gathers over a table of the scene's size: the kernel's fetches are
+            # not uniform (upper levels are hot), so this ratio may exceed 1 and is not the fraction
+            "achieved_over_scene_sized_gather": records / ext_s / 1e9 / max(
+                [v for k, v in ceilings.items() if k.startswith("scene_sized")] or [float("inf")]),
             "algorithmic_gb_per_launch": bytes_per_ray * rays / max(launches, 1) / 1e9,
             "algorithmic_gbs": bytes_per_ray * rays / ext_s / 1e9,
             "algorithmic_gbs_over_hbm_peak": bytes_per_ray * rays / ext_s / 1e9 / HBM_PEAK_GBS,

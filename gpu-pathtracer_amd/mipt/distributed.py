@@ -71,7 +71,19 @@ def make_comm(ctx, rank: int, world: int, prefer_abi: bool = True, group=None):
     dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)
     if int(agreed.item()) == 0:
         return None, "torch.distributed (RCCL)"
-    return mipt.Comm(ctx, raw, world, rank), "libmipt C ABI over RCCL (pt_film_reduce / pt_film_gather_tiles)"
+    comm = None
+    try:
+        comm = mipt.Comm(ctx, raw, world, rank)
+    except mipt.MiptError:
+        comm = None
+    # a rank whose communicator did not come up takes every rank back to torch.distributed
+    made = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(made, op=dist.ReduceOp.MIN, group=group)
+    if int(made.item()) == 0:
+        if comm is not None:
+            comm.close()
+        return None, "torch.distributed (RCCL; the library's communicator did not come up on every rank)"
+    return comm, "libmipt C ABI over RCCL (pt_film_reduce / pt_film_gather_tiles)"
 
 
 def assemble_tiles(packed_sizes: list, pack: Callable[[int, torch.Tensor], None],
