@@ -239,7 +239,10 @@ int pt_context_destroy(pt_context *ctx);
 /* init_device_data, src/main_granite.cpp:180-194: uploads the three storage buffers the
  * shader binds (nodes / vertices / indices, shaders/RadeonRays/bvh.glslh:103-117) and
  * derives the re-laid-out copies the ordered traversal reads.  materials / material_ids
- * may be NULL (a single grey diffuse material is used). */
+ * may be NULL (a single grey diffuse material is used).  The node array must be a tree in the
+ * format of src/bvh/bvh_builder.h:26-34 in which every child's box lies within its parent's
+ * (what a builder that unites its children's boxes produces; PT_ERR_INVALID otherwise): the
+ * hits of the nearer-child-first traversal equal the shader's loop only on such trees. */
 int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
                     uint32_t link_encoding, const float *vtx, uint32_t n_vtx,
                     const int32_t *idx, uint32_t n_tri, const pt_material *materials,
