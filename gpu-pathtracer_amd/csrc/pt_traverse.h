@@ -468,16 +468,18 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                 float ta, tb;
                 const bool ha = intersect_box(st.r, a.x, a.y, a.z, a.w, c.x, c.y, st.bound, ta);
                 const bool hb = intersect_box(st.r, b.x, b.y, b.z, b.w, c.z, c.w, st.bound, tb);
-                const bool take_b = hb & (!ha | (tb < ta));     // the nearer hit child is c1
-                const bool both = ha & hb, none = !(ha | hb);
+                const bool take_b = hb && (!ha || (tb < ta));   // the nearer hit child is c1
+                const bool both = ha && hb, none = !ha && !hb;
                 // No room for the farther child: the lane stops here with the node itself on top
                 // of its stack (the last slot is kept for that), and whoever drives the loop
                 // makes room and repeats the step (stack_service) or gives the ray up.
-                const bool full = both & (st.sp >= stack_cap);
+                const bool full = both && (st.sp >= stack_cap);
                 int32_t next = take_b ? ch.y : ch.x;
                 const int32_t far_c = take_b ? ch.x : ch.y;
-                if (both) stack[st.sp * kTraceBlock] = full ? st.cur : far_c;
-                st.sp += both ? 1 : 0;
+                if (both) {
+                    stack[st.sp * kTraceBlock] = full ? st.cur : far_c;
+                    ++st.sp;
+                }
                 if (none) {
                     --st.sp;
                     next = stack[st.sp * kTraceBlock];
@@ -1240,13 +1242,15 @@ __device__ __forceinline__ void persistent_traverse_two_level(
                     float ta, tb;
                     const bool ha = intersect_box(st.r, a.x, a.y, a.z, a.w, c.x, c.y, st.bound, ta);
                     const bool hb = intersect_box(st.r, b.x, b.y, b.z, b.w, c.z, c.w, st.bound, tb);
-                    const bool take_b = hb & (!ha | (tb < ta));
-                    const bool both = ha & hb, none = !(ha | hb);
-                    const bool full = both & (st.sp >= stack_cap);   // see ordered_advance
+                    const bool take_b = hb && (!ha || (tb < ta));
+                    const bool both = ha && hb, none = !ha && !hb;
+                    const bool full = both && (st.sp >= stack_cap);  // see ordered_advance
                     int32_t next = take_b ? ch.y : ch.x;
                     const int32_t far_c = take_b ? ch.x : ch.y;
-                    if (both) stack[st.sp * kTraceBlock] = full ? st.cur : far_c;
-                    st.sp += both ? 1 : 0;
+                    if (both) {
+                        stack[st.sp * kTraceBlock] = full ? st.cur : far_c;
+                        ++st.sp;
+                    }
                     if (none) {
                         --st.sp;
                         next = stack[st.sp * kTraceBlock];
