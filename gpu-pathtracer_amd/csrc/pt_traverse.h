@@ -55,6 +55,12 @@ __device__ __forceinline__ float4 lds_load4(const LdsFloat4 *p) {
     const NativeFloat4 v = *p;
     return make_float4(v.x, v.y, v.z, v.w);
 }
+typedef int NativeInt2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) NativeInt2 LdsInt2;
+__device__ __forceinline__ int2 lds_load_int2(const LdsFloat4 *p) {
+    const NativeInt2 v = *reinterpret_cast<const LdsInt2 *>(p);
+    return make_int2(v.x, v.y);
+}
 __device__ __forceinline__ void lds_store4(LdsFloat4 *p, const float4 v) {
     NativeFloat4 w;
     w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
@@ -448,17 +454,16 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
         while (mode == 0) {
             if (at_node) {
                 float4 a, b, c;
-                int4 ch;
+                int2 ch;                                    // the two children: 8 of the last 16 bytes
                 if (CACHE && st.cur >= kLdsNodeBase) {      // a node of the top of the tree, in LDS
                     const LdsFloat4 *np = cache + ((st.cur - kLdsNodeBase) << 2);
                     a = lds_load4(np); b = lds_load4(np + 1); c = lds_load4(np + 2);
-                    const float4 cw = lds_load4(np + 3);
-                    ch = make_int4(__float_as_int(cw.x), __float_as_int(cw.y), 0, 0);
+                    ch = lds_load_int2(np + 3);
                     if (COUNT && nl) *nl += 2;
                 } else {
                     const float4 *np = wide_node<BIG>(s, st.cur);
                     a = np[0]; b = np[1]; c = np[2];
-                    ch = reinterpret_cast<const int4 *>(np)[3];
+                    ch = reinterpret_cast<const int2 *>(np + 3)[0];
                 }
 #ifdef PT_WAVE_ITERS
                 if (COUNT && (__ffsll(__ballot(1)) - 1) == (int)(threadIdx.x & 63)) nb += 128;
@@ -1237,7 +1242,7 @@ __device__ __forceinline__ void persistent_traverse_two_level(
                 if (at_node) {
                     const float4 *np = wide_node<BIG>(s, st.cur);
                     const float4 a = np[0], b = np[1], c = np[2];
-                    const int4 ch = reinterpret_cast<const int4 *>(np)[3];
+                    const int2 ch = reinterpret_cast<const int2 *>(np + 3)[0];
                     if (COUNT) nb += 2;
                     float ta, tb;
                     const bool ha = intersect_box(st.r, a.x, a.y, a.z, a.w, c.x, c.y, st.bound, ta);
