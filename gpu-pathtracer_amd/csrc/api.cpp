@@ -57,7 +57,7 @@ void DeviceBuffer::release() {
 } // namespace mipt
 
 namespace mipt {
-ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bool sorted) {
+ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bool coherent) {
     ExtendConfig c;
     c.device = ctx->device;
     c.persistent_blocks = ctx->extend_persistent ? 1 : 0;
@@ -72,17 +72,21 @@ ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bo
     c.spill_entries = ctx->stack_spill.ptr ? kSpillEntries : 0;
     c.max_grid = 0;
     c.xcd_slots = ctx->extend_xcd_slots > 0 ? 1 : 0;
-    // The LDS of a persistent workgroup (measured on MI355X, 262 K-triangle scene in the caches
-    // and 28 M-triangle scene beyond them):
+    // The LDS of a persistent workgroup (measured on MI355X: 262 K-triangle scene in the caches;
+    // 10 M- and 28 M-triangle scenes beyond them, host-built trees of 32-36 levels and GPU-built
+    // ones of 50-70):
     //  - a tree of moderate depth whose records stay in the caches gets by with 16 stack
     //    entries per lane, and 224 cached nodes (the top 7-8 levels) take a tenth off the launch;
-    //  - a deep tree (GPU-built trees over millions of triangles: 50-70 levels) needs its stack,
-    //    or its rays live in the global spill slots: 24 entries + 96 nodes. So does any tree
-    //    beyond the caches, where a spilled entry costs a memory round trip (36-level host
-    //    tree over 28 M triangles, sorted rays: 13.2 ms with 16 + 224, 12.25 ms with 24 + 96);
-    //  - incoherent rays on a scene beyond the Infinity Cache run best with four workgroups per
-    //    compute unit instead of five (fewer rays in flight thrash the caches less): the LDS
-    //    that frees goes to the full stack and 128 nodes.
+    //  - a deep tree needs its stack, or its rays live in the global spill slots: 24 entries +
+    //    96 nodes.  So does any tree beyond the caches, where a spilled entry costs a memory
+    //    round trip (36-level tree over 28 M triangles, rays in origin order: 13.1 ms with
+    //    16 + 224, 12.4 ms with 24 + 96);
+    //  - rays in no particular order (`coherent` false: a trace call whose rays were not sorted)
+    //    on a scene beyond the Infinity Cache run best with three workgroups per compute unit
+    //    instead of five -- fewer rays in flight thrash the caches less: 15.0 -> 13.2 ms on the
+    //    10 M scene, 15.0 -> 14.1 ms on the 28 M scene -- and the LDS that frees goes to the full
+    //    stack and 320 nodes.  The rays of a render pass are not of that kind (a bounce queue is
+    //    in pixel order, so its origins are neighbours): five workgroups, 17.9 against 23.6 ms.
     const DeviceScene &d = scene->dev;
     const bool two_level = d.tlas != nullptr;
     const bool shallow = !two_level && d.wide_depth <= PT_CACHE_MAX_TREE_DEPTH;
@@ -92,9 +96,9 @@ ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bo
     if (shallow && !beyond_caches) {
         stack = 16; cache = 224;
     } else if (!two_level) {
-        if (beyond_caches && !sorted) {
-            stack = PT_LDS_STACK_ENTRIES; cache = 128;
-            if (ctx->extend_blocks_per_cu <= 0) c.blocks_per_cu = 4;
+        if (beyond_caches && !coherent) {
+            stack = PT_LDS_STACK_ENTRIES; cache = 320;
+            if (ctx->extend_blocks_per_cu <= 0) c.blocks_per_cu = 3;
         } else {
             stack = 24; cache = 96;
         }

@@ -79,9 +79,10 @@ struct pt_context {
 namespace mipt {
 // How the traversal kernels of a call on `scene` are launched: the context's options, and where
 // they are left at "auto" the per-scene choice of how a persistent workgroup's LDS is split
-// between the lanes' stacks and the cached top of the tree.  sorted: the call takes its rays in
-// origin-cell order.
-ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bool sorted);
+// between the lanes' stacks and the cached top of the tree.  coherent: neighbouring rays of the
+// call start next to each other (a trace call that takes its rays in origin-cell order, the
+// queues of a render pass).
+ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bool coherent);
 }
 
 struct pt_bvh {

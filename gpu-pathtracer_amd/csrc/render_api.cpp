@@ -276,7 +276,8 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
         work = ctx->counters;
         HIP_CHECK(hipMemsetAsync(work, 0, sizeof(DeviceTraceCounters), st));
     }
-    const ExtendConfig ecfg = make_extend_config(ctx, scene, false);
+    // a pass's queues are in pixel order: neighbouring rays start next to each other
+    const ExtendConfig ecfg = make_extend_config(ctx, scene, true);
     // Kernel timing: one event between every two launches of the call; the span between two
     // neighbouring events is the device time of the launch recorded between them.
     const bool timing = ctx->kernel_timing;

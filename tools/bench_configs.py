@@ -2,6 +2,7 @@
 full size on one GPU, and the BVH-build comparison, printing one JSON line each.
 
     python tools/bench_configs.py [cornell256 cornell1080 sanmiguel lucy gpubuild]
+    MIPT_OPTS="key=int ..." sets pt_context_set_option knobs first.
 """
 import json
 import os
@@ -182,5 +183,8 @@ if __name__ == "__main__":
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
+    for opt in os.environ.get("MIPT_OPTS", "").split():       # e.g. MIPT_OPTS="extend.stack_entries=16"
+        key, _, val = opt.partition("=")
+        ctx.set_option(key, int(val))
     for name in which:
         print(json.dumps(globals()[name](ctx)), flush=True)
