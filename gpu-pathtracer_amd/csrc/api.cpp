@@ -751,6 +751,45 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
     PT_CATCH
 }
 
+int pt_scene_set_face_ids(pt_scene *scene, const int32_t *shape_ids, const int32_t *prim_ids) {
+    if (!scene) return fail(PT_ERR_INVALID, "pt_scene_set_face_ids: null scene");
+    if ((shape_ids == nullptr) != (prim_ids == nullptr))
+        return fail(PT_ERR_INVALID, "pt_scene_set_face_ids: shape_ids and prim_ids must be given together");
+    if (scene->dev.tlas)
+        return fail(PT_ERR_UNSUPPORTED, "pt_scene_set_face_ids: a two-level scene reports the "
+                                        "instance and the triangle of its mesh");
+    PT_TRY
+    pt_context *ctx = scene->ctx;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));       // queries in flight read the old table
+    if (scene->face_ids) {
+        auto &a = scene->allocs;
+        a.erase(std::remove(a.begin(), a.end(), scene->face_ids), a.end());
+        (void)hipFree(scene->face_ids);
+        scene->face_ids = nullptr;
+        scene->dev.face_ids = nullptr;
+    }
+    if (!shape_ids) return PT_OK;
+    const size_t n = scene->dev.n_tri;
+    std::vector<int32_t> pairs(2 * n);
+    for (size_t t = 0; t < n; ++t) {
+        pairs[2 * t] = shape_ids[t];
+        pairs[2 * t + 1] = prim_ids[t];
+    }
+    void *buf = nullptr;
+    HIP_CHECK(hipMalloc(&buf, 8 * n));
+    const hipError_t e = hipMemcpy(buf, pairs.data(), 8 * n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(buf);
+        return hip_fail(e, "pt_scene_set_face_ids upload");
+    }
+    scene->allocs.push_back(buf);
+    scene->face_ids = buf;
+    scene->dev.face_ids = (const int2 *)buf;
+    return PT_OK;
+    PT_CATCH
+}
+
 uint32_t pt_scene_node_count(const pt_scene *scene) { return scene ? scene->dev.n_nodes : 0; }
 uint32_t pt_scene_tree_depth(const pt_scene *scene) { return scene ? scene->dev.wide_depth : 0; }
 uint32_t pt_scene_link_encoding(const pt_scene *scene) { return scene ? scene->dev.link_enc : 0; }
@@ -821,6 +860,7 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
         launch_trace_ordered(st, scene->dev, rays_dev, hits_dev, n, fixup, ctx->counters, count, cfg,
                              &ctx->sort_scratch, bracket);
     }
+    launch_map_face_ids(st, hits_dev, n, scene->dev.face_ids);
     HIP_CHECK(hipGetLastError());
     if (stats) {
         DeviceTraceCounters c;

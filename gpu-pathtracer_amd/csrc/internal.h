@@ -101,6 +101,7 @@ struct pt_scene {
     pt_context *ctx = nullptr;
     mipt::DeviceScene dev{};
     std::vector<void *> allocs;
+    void *face_ids = nullptr;            // device table of pt_scene_set_face_ids (also in allocs)
     // two-level scenes: where each mesh's skip-link nodes lie in dev.nodes
     std::vector<uint32_t> mesh_node_off, mesh_node_count;
     void release() {

@@ -56,6 +56,10 @@ struct DeviceScene {
     // each triangle's leaf (null otherwise).  Lets a ray with two near-equal candidates be
     // decided at those two leaves instead of by a walk over the whole tree.
     const int32_t *tri_leaf;
+    // Optional: what a hit on each triangle reports as (shapeid, primid) from the stand-alone
+    // closest-hit queries, the Face records of the reference's multi-mesh builder
+    // (src/bvh/RadeonRays/intersector_skip_links.h:82-92).  Null: (0, triangle index).
+    const int2 *face_ids;
     // Two-level scenes only (tlas != nullptr): a skip-link tree over the instances whose leaf
     // payload is an instance index (the "top-level BVH" of src/bvh/bvh_builder.h:31); the
     // arrays above then hold every mesh back to back, in object space, except stris, which
@@ -83,6 +87,8 @@ void launch_build_top_cache(hipStream_t st, const float4 *wnodes, uint32_t n_wno
                             int32_t *global_index, uint32_t *n_out);
 // Fills tri_leaf[0..n_tri) (preset to -1 by the caller) with the index of each triangle's leaf
 // among the n_nodes skip-link nodes; *multi becomes non-zero if some triangle has several.
+// Rewrites (shapeid, primid) of every hit record in hits[0..n) through face_ids.
+void launch_map_face_ids(hipStream_t st, pt_hit *hits, uint64_t n, const int2 *face_ids);
 void launch_build_tri_leaf(hipStream_t st, const float4 *nodes, uint32_t n_nodes, uint32_t link_enc,
                            uint32_t n_tri, int32_t *tri_leaf, uint32_t *multi);
 

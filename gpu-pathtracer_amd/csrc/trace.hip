@@ -262,7 +262,20 @@ __global__ void k_build_tri_leaf(const float4 *nodes, uint32_t n_nodes, uint32_t
     if (payload < 0 || (uint32_t)payload >= n_tri) return;
     if (atomicCAS(&tri_leaf[payload], -1, (int32_t)i) != -1) atomicOr(multi, 1u);
 }
+__global__ void k_map_face_ids(pt_hit *hits, uint64_t n, const int2 *face_ids) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    int2 *h = reinterpret_cast<int2 *>(hits + i);      // shapeid, primid
+    const int32_t tri = h->y;
+    if (tri >= 0) *h = face_ids[tri];
+}
 } // namespace
+
+void launch_map_face_ids(hipStream_t st, pt_hit *hits, uint64_t n, const int2 *face_ids) {
+    if (!n || !face_ids) return;
+    hipLaunchKernelGGL(k_map_face_ids, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, st, hits, n,
+                       face_ids);
+}
 
 void launch_build_tri_leaf(hipStream_t st, const float4 *nodes, uint32_t n_nodes, uint32_t link_enc,
                            uint32_t n_tri, int32_t *tri_leaf, uint32_t *multi) {
@@ -479,6 +492,7 @@ int launch_trace_static(hipStream_t st, int device, const DeviceScene &s, const 
         launch_trace_skiplink(st, s, rays, hits, n, (flags & PT_TRACE_MOLLER_TRUMBORE) != 0, nullptr);
     else
         launch_trace_ordered(st, s, rays, hits, n, fixup, counters, false, cfg, nullptr);
+    launch_map_face_ids(st, hits, n, s.face_ids);
     return PT_OK;
 }
 

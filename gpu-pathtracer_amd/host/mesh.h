@@ -10,6 +10,11 @@ struct pt_mesh {
     std::vector<float> vtx;             // xyz packed
     std::vector<int32_t> idx;           // 3 per triangle
     std::vector<int32_t> mat_ids;       // 1 per triangle
+    // OBJ files: the shape (o / g group) each triangle belongs to and its position among that
+    // shape's triangles -- the shape_id / prim_id of the reference's Face records
+    // (src/bvh/RadeonRays/intersector_skip_links.h:82-92).  Empty for other sources.
+    std::vector<int32_t> shape_ids, shape_prim_ids;
+    uint32_t n_shapes = 0;
     std::vector<pt_material> materials;
 };
 

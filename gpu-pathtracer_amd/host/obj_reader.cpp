@@ -4,7 +4,8 @@
 // the packed vertex positions (attrib.vertices) and, per face corner, the
 // position index (mesh.indices[].vertex_index), with polygons triangulated as
 // fans.  All shapes of the file are merged into one mesh (the reference uses
-// shapes[0] only, src/main.cpp:862).  Additionally keeps per-triangle material
+// shapes[0] only, src/main.cpp:862), with each triangle's shape and its index within the
+// shape kept beside it.  Additionally keeps per-triangle material
 // ids and the Kd/Ks/Ke/Ns/Pr entries of the MTL file, which the shading
 // kernels need and the reference never reads.
 #include <cctype>
@@ -90,6 +91,9 @@ int pt_obj_load(const char *path, pt_mesh **out) {
         auto mesh = std::make_unique<pt_mesh>();
         std::map<std::string, int> mat_by_name;
         int cur_mat = -1;
+        // shapes as tinyobj::LoadObj cuts them (src/main.cpp:860): an `o` or `g` statement ends
+        // the running shape if it has faces
+        int32_t cur_shape = 0, faces_in_shape = 0;
         std::string line;
         size_t lineno = 0;
         std::vector<int32_t> corners;
@@ -130,6 +134,13 @@ int pt_obj_load(const char *path, pt_mesh **out) {
                     mesh->idx.push_back(corners[k]);
                     mesh->idx.push_back(corners[k + 1]);
                     mesh->mat_ids.push_back(cur_mat);
+                    mesh->shape_ids.push_back(cur_shape);
+                    mesh->shape_prim_ids.push_back(faces_in_shape++);
+                }
+            } else if (tag == "o" || tag == "g") {
+                if (faces_in_shape > 0) {
+                    ++cur_shape;
+                    faces_in_shape = 0;
                 }
             } else if (tag == "mtllib") {
                 std::string name;
@@ -154,6 +165,7 @@ int pt_obj_load(const char *path, pt_mesh **out) {
                 }
                 m = def;
             }
+        mesh->n_shapes = (uint32_t)(faces_in_shape > 0 ? cur_shape + 1 : cur_shape);
         *out = mesh.release();
         return PT_OK;
     } catch (const std::bad_alloc &) {
@@ -170,6 +182,13 @@ const float *pt_mesh_vertices(const pt_mesh *m) { return m ? m->vtx.data() : nul
 const int32_t *pt_mesh_indices(const pt_mesh *m) { return m ? m->idx.data() : nullptr; }
 const int32_t *pt_mesh_material_ids(const pt_mesh *m) { return m ? m->mat_ids.data() : nullptr; }
 const pt_material *pt_mesh_materials(const pt_mesh *m) { return m ? m->materials.data() : nullptr; }
+uint32_t pt_mesh_shape_count(const pt_mesh *m) { return m ? m->n_shapes : 0; }
+const int32_t *pt_mesh_shape_ids(const pt_mesh *m) {
+    return m && !m->shape_ids.empty() ? m->shape_ids.data() : nullptr;
+}
+const int32_t *pt_mesh_shape_prim_ids(const pt_mesh *m) {
+    return m && !m->shape_prim_ids.empty() ? m->shape_prim_ids.data() : nullptr;
+}
 
 // src/main.cpp:865-880: centre on the bounding box and divide by its largest extent.
 int pt_mesh_normalize_unit_cube(pt_mesh *m) {

@@ -127,6 +127,9 @@ _PROTOS = {
     "pt_mesh_indices": (_vp, [_vp]),
     "pt_mesh_material_ids": (_vp, [_vp]),
     "pt_mesh_materials": (_vp, [_vp]),
+    "pt_mesh_shape_count": (C.c_uint32, [_vp]),
+    "pt_mesh_shape_ids": (_vp, [_vp]),
+    "pt_mesh_shape_prim_ids": (_vp, [_vp]),
     "pt_mesh_normalize_unit_cube": (C.c_int, [_vp]),
     "pt_mesh_destroy": (C.c_int, [_vp]),
     "pt_context_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
@@ -164,6 +167,7 @@ _PROTOS = {
     "pt_scene_node_count": (C.c_uint32, [_vp]),
     "pt_scene_link_encoding": (C.c_uint32, [_vp]),
     "pt_scene_tree_depth": (C.c_uint32, [_vp]),
+    "pt_scene_set_face_ids": (C.c_int, [_vp, _vp, _vp]),
     "pt_scene_read_nodes": (C.c_int, [_vp, _vp]),
     "pt_trace_closest": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32,
                                    C.POINTER(TraceStats)]),
@@ -347,6 +351,11 @@ class Mesh:
             self.idx = grab(lib.pt_mesh_indices(h), nt * 12, np.int32).reshape(-1, 3)
             self.material_ids = grab(lib.pt_mesh_material_ids(h), nt * 4, np.int32)
             self.materials = grab(lib.pt_mesh_materials(h), nm * 48, material_dtype)
+            # OBJ files: each triangle's shape (o / g group) and its index within the shape
+            self.n_shapes = int(lib.pt_mesh_shape_count(h))
+            sp, pp = lib.pt_mesh_shape_ids(h), lib.pt_mesh_shape_prim_ids(h)
+            self.shape_ids = grab(sp, nt * 4, np.int32) if sp else None
+            self.shape_prim_ids = grab(pp, nt * 4, np.int32) if pp else None
         finally:
             lib.pt_mesh_destroy(h)
 
@@ -510,6 +519,18 @@ class Scene:
 
     def tree_depth(self) -> int:
         return int(lib.pt_scene_tree_depth(self._h))
+
+    def set_face_ids(self, shape_ids, prim_ids) -> None:
+        """pt_scene_set_face_ids: what the closest-hit queries report per triangle (None, None
+        removes the table)."""
+        if shape_ids is None and prim_ids is None:
+            _check(lib.pt_scene_set_face_ids(self._h, None, None))
+            return
+        a = np.ascontiguousarray(shape_ids, dtype=np.int32)
+        b = np.ascontiguousarray(prim_ids, dtype=np.int32)
+        if a.shape != b.shape or a.ndim != 1:
+            raise ValueError("shape_ids and prim_ids must be one-dimensional and of equal length")
+        _check(lib.pt_scene_set_face_ids(self._h, _ptr(a), _ptr(b)))
 
     def read_nodes(self) -> np.ndarray:
         """The scene's skip-link node array."""

@@ -175,6 +175,13 @@ const float *pt_mesh_vertices(const pt_mesh *m);        /* xyz packed */
 const int32_t *pt_mesh_indices(const pt_mesh *m);       /* 3 per triangle */
 const int32_t *pt_mesh_material_ids(const pt_mesh *m);  /* 1 per triangle */
 const pt_material *pt_mesh_materials(const pt_mesh *m);
+/* OBJ files only (0 / NULL otherwise): the shapes tinyobj::LoadObj would cut the file into
+ * (src/main.cpp:860), as one shape index and one index within the shape per triangle -- the
+ * shape_id / prim_id of the Face records the legacy builder fills
+ * (src/bvh/RadeonRays/intersector_skip_links.cpp:236-264).  See pt_scene_set_face_ids. */
+uint32_t pt_mesh_shape_count(const pt_mesh *m);
+const int32_t *pt_mesh_shape_ids(const pt_mesh *m);       /* 1 per triangle */
+const int32_t *pt_mesh_shape_prim_ids(const pt_mesh *m);  /* 1 per triangle */
 /* "Scale model into unit cube", src/main.cpp:865-880. */
 int pt_mesh_normalize_unit_cube(pt_mesh *m);
 int pt_mesh_destroy(pt_mesh *m);
@@ -318,6 +325,17 @@ uint32_t pt_scene_top_node_count(const pt_scene *scene);
 int pt_scene_read_top_nodes(pt_scene *scene, pt_bbox *nodes);
 uint32_t pt_scene_mesh_node_count(const pt_scene *scene, uint32_t mesh);
 int pt_scene_read_mesh_nodes(pt_scene *scene, uint32_t mesh, pt_bbox *nodes);
+
+/* Several meshes flattened into one scene: what a hit on each triangle reports.  The
+ * reference's multi-mesh builder writes one Face{idx[3], shape_id, prim_id} per triangle
+ * (src/bvh/RadeonRays/intersector_skip_links.h:82-92, filled at intersector_skip_links.cpp:236-264)
+ * for the shader to return as isect.shapeid / isect.primid (shaders/RadeonRays/bvh.glslh:342-343,
+ * commented out in the checked-in shader, which returns 0 and the triangle index).  With a
+ * table set, pt_trace_closest* report shapeid = shape_ids[t], primid = prim_ids[t] for a hit
+ * on triangle t of the scene's index buffer; misses are unchanged.  n_triangles entries each;
+ * NULL, NULL removes the table.  pt_render and its statistics are not affected.  Single-level
+ * scenes only (a two-level scene reports instance and mesh triangle).  Blocking. */
+int pt_scene_set_face_ids(pt_scene *scene, const int32_t *shape_ids, const int32_t *prim_ids);
 
 /* The scene's skip-link array (what pt_scene_create was given, or what pt_scene_build made):
  * for validation, caching, or a CPU traversal of the same tree.  Blocking. */

@@ -253,6 +253,54 @@ def test_pairs_of_near_coincident_triangles(mipt, oracle, scenes, gpu_ctx):
         sc.close()
 
 
+def test_face_ids_of_a_flattened_multi_mesh_scene(mipt, oracle, scenes, gpu_ctx):
+    """Several meshes in one tree (intersector_skip_links.cpp:169-268): a hit reports the
+    shape_id / prim_id of its Face record instead of 0 / triangle index, in every query mode,
+    on host-built and GPU-built trees; misses and everything else in the record stay as they are,
+    and removing the table restores the shader's checked-in behaviour."""
+    vtx, idx, _, _ = scenes.random_soup(3000, seed=41)
+    n = idx.shape[0]
+    shape = (np.arange(n) // 700).astype(np.int32) + 10            # five "meshes", ids 10..14
+    prim = (np.arange(n) % 700).astype(np.int32)
+    rays = random_rays(60000, 43, dtype=mipt.ray_dtype)
+    nodes = _build(mipt, vtx, idx)
+    want = oracle.closest(nodes, vtx, idx, rays, nthreads=8)
+    hit = want["primid"] >= 0
+    mapped = want.copy()
+    mapped["shapeid"][hit] = shape[want["primid"][hit]]
+    mapped["primid"][hit] = prim[want["primid"][hit]]
+    assert hit.sum() > 1000 and (~hit).sum() > 1000
+    for sc in (mipt.Scene(gpu_ctx, nodes, vtx, idx), ):
+        try:
+            sc.set_face_ids(shape, prim)
+            for flags in (mipt.PT_TRACE_DEFAULT, mipt.PT_TRACE_EXACT_ORDER):
+                assert len(same_hits(sc.trace_closest(rays, flags), mapped)) == 0
+            d_r = __import__("torch").from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
+            d_h = __import__("torch").empty_like(d_r)
+            sc.trace_closest_device_static(d_r.data_ptr(), len(rays), d_h.data_ptr())
+            gpu_ctx.synchronize()
+            got = d_h.cpu().numpy().view(mipt.hit_dtype).reshape(-1)
+            assert len(same_hits(got, mapped)) == 0
+            sc.set_face_ids(None, None)
+            assert len(same_hits(sc.trace_closest(rays), want)) == 0
+            with pytest.raises(mipt.MiptError, match="together"):
+                mipt._check(mipt.lib.pt_scene_set_face_ids(sc._h, mipt._ptr(shape), None))
+        finally:
+            sc.close()
+    # a tree built on the GPU: compare with the walk of its own array
+    sc = mipt.Scene(gpu_ctx, None, vtx, idx)
+    try:
+        w2 = oracle.closest(sc.read_nodes(), vtx, idx, rays, nthreads=8)
+        h2 = w2["primid"] >= 0
+        m2 = w2.copy()
+        m2["shapeid"][h2] = shape[w2["primid"][h2]]
+        m2["primid"][h2] = prim[w2["primid"][h2]]
+        sc.set_face_ids(shape, prim)
+        assert len(same_hits(sc.trace_closest(rays), m2)) == 0
+    finally:
+        sc.close()
+
+
 def _comb_tree(oracle, vtx, idx):
     """A hand-made skip-link tree of depth n: inner node i holds triangle i and inner node i+1
     (pre-order: inner_0, leaf_0, inner_1, leaf_1, ..., leaf_{n-2}, leaf_{n-1}; float links)."""

@@ -176,6 +176,17 @@ def test_obj_reader(mipt, scenes, tmp_path):
     m = mipt.Mesh(str(p))
     np.testing.assert_array_equal(m.idx, [[0, 1, 2], [0, 2, 3], [0, 3, 4], [0, 1, 2]])
     assert m.materials.shape[0] == 1 and (m.material_ids == 0).all()
+    assert m.n_shapes == 1 and (m.shape_ids == 0).all()
+    np.testing.assert_array_equal(m.shape_prim_ids, [0, 1, 2, 3])
+    # shapes as tinyobj cuts them: an o / g statement ends a shape that has faces; each triangle
+    # keeps its shape and its index within it (the Face records of intersector_skip_links.h:82-92)
+    q = tmp_path / "shapes.obj"
+    q.write_text("o first\ng also_first\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n"
+                 "g second\nf 1 2 3\nf 2 3 4\no third\no still_third\nf 1 3 4\ng empty_tail\n")
+    ms = mipt.Mesh(str(q))
+    assert ms.n_shapes == 3
+    np.testing.assert_array_equal(ms.shape_ids, [0, 0, 1, 1, 2])
+    np.testing.assert_array_equal(ms.shape_prim_ids, [0, 1, 0, 1, 0])
     # "scale model into unit cube" (src/main.cpp:865-880)
     m = mipt.Mesh(str(p), normalize=True)
     ext = m.vtx.max(axis=0) - m.vtx.min(axis=0)

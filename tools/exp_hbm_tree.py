@@ -17,6 +17,8 @@ d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
 d_h = torch.empty_like(d_r)
 ctx.set_kernel_timing(True)
 configs = [("radix+8", 0, 8), ("radix+16", 0, 16)]
+if os.environ.get("ONLY"):
+    configs = [c for c in configs if c[0] == os.environ["ONLY"]]
 for o in sys.argv[1:]:
     k_, _, v_ = o.partition("=")
     ctx.set_option(k_, int(v_))
@@ -35,10 +37,18 @@ for name, radius, passes in configs:
     ctx.synchronize()
     build_s = time.perf_counter() - t0
     stc = sc.trace_closest_device_counted(d_r.data_ptr(), n, d_h.data_ptr())
-    for split in os.environ.get("SPLITS", "-1:-1").split():
-        S, C = split.split(":")
-        ctx.set_option("extend.stack_entries", int(S))
-        ctx.set_option("extend.cache_nodes", int(C))
+    # SPLITS: "stack:nodes ..." of the persistent workgroups' LDS; or SETS: "key=int,key=int ..."
+    # option sets, each applied in turn (options stay set: give every key in every set)
+    variants = os.environ.get("SETS", "").split() or os.environ.get("SPLITS", "-1:-1").split()
+    for split in variants:
+        if "=" in split:
+            for kv in split.split(","):
+                k_, _, v_ = kv.partition("=")
+                ctx.set_option(k_, int(v_))
+        else:
+            S, C = split.split(":")
+            ctx.set_option("extend.stack_entries", int(S))
+            ctx.set_option("extend.cache_nodes", int(C))
         sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr()); ctx.synchronize()
         k = 0.0
         for _ in range(3):

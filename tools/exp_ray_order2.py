@@ -36,11 +36,25 @@ def rate(sc, ctx, rays):
 def main():
     ctx = mipt.Context(0)
     st = torch.cuda.Stream(); torch.cuda.set_stream(st); ctx.set_stream(st.cuda_stream)
-    vtx, idx, mats, mids = scenes.atrium(262144, seed=42)
-    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
-    sc = mipt.Scene(ctx, nodes, vtx, idx)
-    W, H = 1920, 1080
-    rays = np.tile(ctx.raygen(scenes.atrium_camera(W / H), W, H), 2)     # 2 spp
+    if "clutter" in sys.argv[1:]:
+        # a scene beyond the caches (10 M triangles, 1.1 GB of records), launched like a render
+        # pass launches (no sort inside the call, five workgroups per CU)
+        vtx, idx, mats, mids = scenes.clutter(10_000_000, seed=11)
+        nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx),
+                               mipt.bvh_options(**{"bvh.builder": "sah", "mipt.link_encoding": "int"}))
+        sc = mipt.Scene(ctx, nodes, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
+        for k, v in (("trace.sort_rays", 0), ("extend.blocks_per_cu", 5), ("extend.stack_entries", 24),
+                     ("extend.cache_nodes", 96)):
+            ctx.set_option(k, v)
+        W, H = 3840, 2160
+        cam = mipt.look_at_camera((-17.0, 10.5, -16.0), (3.0, 1.0, 2.0), fovy_deg=50.0, aspect=W / H)
+        rays = ctx.raygen(cam, W, H)
+    else:
+        vtx, idx, mats, mids = scenes.atrium(262144, seed=42)
+        nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+        sc = mipt.Scene(ctx, nodes, vtx, idx)
+        W, H = 1920, 1080
+        rays = np.tile(ctx.raygen(scenes.atrium_camera(W / H), W, H), 2)     # 2 spp
     rng = np.random.default_rng(3)
     lo, hi = vtx.min(0), vtx.max(0)
     for bounce in range(5):
