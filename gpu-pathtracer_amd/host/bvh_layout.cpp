@@ -2,8 +2,10 @@
 // two-child re-layout read by the ordered GPU traversal.
 #include "bvh.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -174,6 +176,57 @@ void build_wide_layout(const BvhTree &t, const float *vtx, uint32_t n_vtx, const
     {
         int32_t ni = 0, nl = 0;
         for (size_t i = 0; i < n; ++i) slot[i] = t.right[i] >= 0 ? ni++ : ~(nl++);
+    }
+    // Experiment knob (tools/exp_node_order.py): another order of the two-child nodes in memory.
+    // MIPT_WIDE_ORDER = random | bfs | treelet:<nodes>.  The root stays node 0; no result depends
+    // on the order.
+    if (const char *order = std::getenv("MIPT_WIDE_ORDER")) {
+        const std::string kind(order);
+        std::vector<size_t> seq;                 // tree nodes (inner only) in their new order
+        seq.reserve(n_inner);
+        if (kind == "bfs" || kind == "random") {
+            std::vector<size_t> q{0};
+            for (size_t h = 0; h < q.size(); ++h) {
+                const size_t i = q[h];
+                if (t.right[i] < 0) continue;
+                seq.push_back(i);
+                q.push_back(i + 1);
+                q.push_back((size_t)t.right[i]);
+            }
+            if (kind == "random") {
+                uint64_t state = 0x9E3779B97F4A7C15ull;
+                for (size_t k = seq.size(); k > 2; --k) {     // Fisher-Yates over seq[1..]
+                    state = state * 6364136223846793005ull + 1442695040888963407ull;
+                    const size_t j = 1 + (size_t)((state >> 33) % (k - 1));
+                    std::swap(seq[k - 1], seq[j]);
+                }
+            }
+        } else if (kind.rfind("treelet:", 0) == 0) {
+            const size_t cap = std::max<size_t>(1, std::strtoull(kind.c_str() + 8, nullptr, 10));
+            std::vector<size_t> roots{0};        // treelet roots still to be laid out (a stack)
+            std::vector<size_t> q;
+            while (!roots.empty()) {
+                const size_t r = roots.back();
+                roots.pop_back();
+                if (t.right[r] < 0) continue;
+                q.assign(1, r);                   // breadth first from r, at most cap inner nodes
+                size_t taken = 0;
+                for (size_t h = 0; h < q.size(); ++h) {
+                    const size_t i = q[h];
+                    if (t.right[i] < 0) continue;
+                    if (taken == cap) {
+                        roots.push_back(i);
+                        continue;
+                    }
+                    seq.push_back(i);
+                    ++taken;
+                    q.push_back(i + 1);
+                    q.push_back((size_t)t.right[i]);
+                }
+            }
+        }
+        if (seq.size() == n_inner && n_leaves > 1)
+            for (size_t k = 0; k < seq.size(); ++k) slot[seq[k]] = (int32_t)k;
     }
     auto fill_tri = [&](size_t node) {
         const int32_t p = t.prim[node];
