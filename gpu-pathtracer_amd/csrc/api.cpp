@@ -578,7 +578,7 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     UP(d_vtx, vtx, sizeof(float) * 3 * (size_t)n_vtx);
     UP(d_idx, idx, sizeof(int32_t) * 3 * (size_t)n_tri);
     UP(d_wn, wide.nodes.data(), sizeof(WideNode) * wide.nodes.size());
-    UP(d_wt, wide.tris.data(), sizeof(TriRecord) * wide.tris.size());
+    UP(d_wt, wide.tris.data(), sizeof(WideTriRecord) * wide.tris.size());
     UP(d_st, stris.data(), sizeof(TriRecord) * stris.size());
     UP(d_mid, mids.data(), sizeof(int32_t) * mids.size());
     UP(d_mat, mats.data(), sizeof(pt_material) * mats.size());
@@ -697,7 +697,7 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
               upload(&d_mat, mats.data(), sizeof(pt_material) * mats.size()) &&
               dev_alloc(&d_nodes, sizeof(pt_bbox) * (size_t)n_nodes) &&
               dev_alloc(&d_wn, sizeof(WideNode) * (size_t)(n_tri - 1)) &&
-              dev_alloc(&d_wt, sizeof(TriRecord) * (size_t)n_tri) &&
+              dev_alloc(&d_wt, sizeof(WideTriRecord) * (size_t)n_tri) &&
               dev_alloc(&d_st, sizeof(TriRecord) * (size_t)n_tri);
     if (ok && !light_tri.empty())
         ok = upload(&d_lt, light_tri.data(), sizeof(int32_t) * light_tri.size()) &&

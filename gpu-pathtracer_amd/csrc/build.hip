@@ -266,8 +266,8 @@ __global__ __launch_bounds__(kB) void k_emit_inner(EmitArgs a) {
     const float4 *bl = cl >= 0 ? a.ibox + 2 * (size_t)cl : a.boxes + 2 * (size_t)a.vals[~cl];
     const float4 *br = cr >= 0 ? a.ibox + 2 * (size_t)cr : a.boxes + 2 * (size_t)a.vals[~cr];
     const float4 lmin = bl[0], lmax = bl[1], rmin = br[0], rmax = br[1];
-    const int32_t ref_l = cl >= 0 ? (int32_t)(a.first[cl] + lt + 1) : ~(3 * (~cl));
-    const int32_t ref_r = cr >= 0 ? (int32_t)(a.first[cr] + lt) : ~(3 * (~cr));
+    const int32_t ref_l = cl >= 0 ? (int32_t)(a.first[cl] + lt + 1) : ~(PT_TRI_RECORD_16B * (~cl));
+    const int32_t ref_r = cr >= 0 ? (int32_t)(a.first[cr] + lt) : ~(PT_TRI_RECORD_16B * (~cr));
     float4 *w = a.wnodes + 4 * (size_t)(f + lt);
     w[0] = make_float4(lmin.x, lmax.x, lmin.y, lmax.y);
     w[1] = make_float4(rmin.x, rmax.x, rmin.y, rmax.y);
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kB) void k_emit_leaf(EmitArgs a) {
     const int32_t i0 = a.idx[3 * (size_t)tri], i1 = a.idx[3 * (size_t)tri + 1],
                   i2 = a.idx[3 * (size_t)tri + 2];
     const float *v0 = a.vtx + 3 * (size_t)i0, *v1 = a.vtx + 3 * (size_t)i1, *v2 = a.vtx + 3 * (size_t)i2;
-    float4 *r = a.wtris + 3 * (size_t)l;
+    float4 *r = a.wtris + PT_TRI_RECORD_16B * (size_t)l;
     r[0] = make_float4(v0[0], v0[1], v0[2], v1[0]);
     r[1] = make_float4(v1[1], v1[2], v2[0], v2[1]);
     r[2] = make_float4(v2[2], __int_as_float((int32_t)tri), 0.f, 0.f);
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(kB) void k_ploc_emit(PlocEmitArgs a) {
                       i2 = a.idx[3 * (size_t)tri + 2];
         const float *v0 = a.vtx + 3 * (size_t)i0, *v1 = a.vtx + 3 * (size_t)i1,
                     *v2 = a.vtx + 3 * (size_t)i2;
-        float4 *r = a.wtris + 3 * (size_t)before;        // leaf slot = leaves before it
+        float4 *r = a.wtris + PT_TRI_RECORD_16B * (size_t)before;        // leaf slot = leaves before it
         r[0] = make_float4(v0[0], v0[1], v0[2], v1[0]);
         r[1] = make_float4(v1[1], v1[2], v2[0], v2[1]);
         r[2] = make_float4(v2[2], __int_as_float((int32_t)tri), 0.f, 0.f);
@@ -461,8 +461,8 @@ __global__ __launch_bounds__(kB) void k_ploc_emit(PlocEmitArgs a) {
     const float4 lmin = a.t.box[2 * (size_t)l], lmax = a.t.box[2 * (size_t)l + 1];
     const float4 rmin = a.t.box[2 * (size_t)r], rmax = a.t.box[2 * (size_t)r + 1];
     // inner nodes are numbered among themselves in pre-order: position minus leaves before
-    const int32_t ref_l = l >= a.n ? (int32_t)(a.t.pos[l] - a.t.before[l]) : ~(int32_t)(3 * a.t.before[l]);
-    const int32_t ref_r = r >= a.n ? (int32_t)(a.t.pos[r] - a.t.before[r]) : ~(int32_t)(3 * a.t.before[r]);
+    const int32_t ref_l = l >= a.n ? (int32_t)(a.t.pos[l] - a.t.before[l]) : ~(int32_t)(PT_TRI_RECORD_16B * a.t.before[l]);
+    const int32_t ref_r = r >= a.n ? (int32_t)(a.t.pos[r] - a.t.before[r]) : ~(int32_t)(PT_TRI_RECORD_16B * a.t.before[r]);
     float4 *w = a.wnodes + 4 * (size_t)(pos - before);
     w[0] = make_float4(lmin.x, lmax.x, lmin.y, lmax.y);
     w[1] = make_float4(rmin.x, rmax.x, rmin.y, rmax.y);

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_instance_shading_records(DeviceScene s,
 }
 
 // Child indices of one mesh's two-child nodes from mesh-local to scene-wide (see
-// enter_instance): inner child + node_base; leaf child ~(16-byte position) + 3 * record base.
+// enter_instance): inner child + node_base; leaf child ~(16-byte position) + record size * record base.
 __global__ __launch_bounds__(256) void k_rebase_children(int4 *child_words, uint32_t n_nodes,
                                                          int32_t node_base, int32_t tri_base16) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -58,7 +58,7 @@ void launch_rebase_children(hipStream_t st, float4 *wnodes, uint32_t n_nodes, ui
     if (!n_nodes) return;
     hipLaunchKernelGGL(k_rebase_children, dim3((n_nodes + 255) / 256), dim3(256), 0, st,
                        reinterpret_cast<int4 *>(wnodes), n_nodes, (int32_t)node_base,
-                       (int32_t)(3 * tri_record_base));
+                       (int32_t)(PT_TRI_RECORD_16B * tri_record_base));
 }
 
 void launch_instance_shading_records(hipStream_t st, const DeviceScene &s,

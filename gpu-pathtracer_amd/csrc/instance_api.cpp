@@ -200,7 +200,7 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             return fail(PT_ERR_UNSUPPORTED,
                         "pt_scene_create_instanced: more nodes than a child index can name");
         char *d_wnodes = (char *)dev_alloc(sizeof(WideNode) * ((size_t)tot_wnodes + top_room));
-        char *d_wtris = (char *)dev_alloc(sizeof(TriRecord) * (size_t)tot_wtris);
+        char *d_wtris = (char *)dev_alloc(sizeof(WideTriRecord) * (size_t)tot_wtris);
         sc->mesh_node_off.resize(n_meshes);
         sc->mesh_node_count.resize(n_meshes);
         DeviceBuffer scratch;
@@ -213,19 +213,19 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             int32_t *mi = (int32_t *)(d_idx + sizeof(int32_t) * 3 * (size_t)pl.tri);
             float4 *mn = (float4 *)(d_nodes + sizeof(pt_bbox) * (size_t)pl.node);
             float4 *mw = (float4 *)(d_wnodes + sizeof(WideNode) * (size_t)pl.wnode);
-            float4 *mt = (float4 *)(d_wtris + sizeof(TriRecord) * (size_t)pl.wtri);
+            float4 *mt = (float4 *)(d_wtris + sizeof(WideTriRecord) * (size_t)pl.wtri);
             copy_in(mv, d.vertices, sizeof(float) * 3 * (size_t)d.n_vertices);
             copy_in(mi, d.indices, sizeof(int32_t) * 3 * (size_t)d.n_triangles);
             if (!pl.on_gpu) {
                 // child indices become scene-wide: an inner child is the index of a two-child
                 // node, a leaf child the complement of its record's position in 16-byte units
-                const int32_t node_base = (int32_t)pl.wnode, tri_base = 3 * (int32_t)pl.wtri;
+                const int32_t node_base = (int32_t)pl.wnode, tri_base = PT_TRI_RECORD_16B * (int32_t)pl.wtri;
                 for (WideNode &w : pl.wide.nodes)
                     for (int c = 0; c < 2; ++c)
                         w.child[c] = w.child[c] >= 0 ? w.child[c] + node_base : ~(~w.child[c] + tri_base);
                 copy_in(mn, pl.nodes, sizeof(pt_bbox) * (size_t)pl.n_nodes);
                 copy_in(mw, pl.wide.nodes.data(), sizeof(WideNode) * pl.wide.nodes.size());
-                copy_in(mt, pl.wide.tris.data(), sizeof(TriRecord) * pl.wide.tris.size());
+                copy_in(mt, pl.wide.tris.data(), sizeof(WideTriRecord) * pl.wide.tris.size());
                 pl.wide = WideBvh();
                 continue;
             }

@@ -76,9 +76,11 @@ struct DeviceScene {
 constexpr int32_t kLdsNodeBase = 1 << 30;
 // What the child encodings can name: two-child nodes below kLdsNodeBase, triangle records by
 // their position in 16-byte units (three per record) in 31 bits.
-constexpr uint64_t kMaxWideNodes = (1ull << 30) - 1, kMaxWideTris = 700000000ull;
+constexpr uint64_t kMaxWideNodes = (1ull << 30) - 1,
+                   kMaxWideTris = 2100000000ull / PT_TRI_RECORD_16B;     // 700 M packed records
 inline bool needs_big_addresses(uint64_t n_wnodes, uint64_t n_wtris) {
-    return n_wnodes > (1ull << 26) || n_wtris > 89000000ull;
+    // byte offsets of the records must fit 32 bits
+    return n_wnodes > (1ull << 26) || n_wtris > 267000000ull / PT_TRI_RECORD_16B;
 }
 constexpr int kNodeCacheMax = PT_LDS_NODE_CACHE_MAX;
 // Fills top_cache and top_global (room for kNodeCacheMax nodes each) from wnodes and writes the

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/mipt.h"
+#include "../../include/pt_config.h"
 
 namespace mipt {
 
@@ -51,7 +52,7 @@ void tree_from_skip_links(const pt_bbox *nodes, uint32_t n_nodes, uint32_t link_
 //   lo.x/y/z/w = c0.min.x, c0.max.x, c0.min.y, c0.max.y   (16-byte vector 0)
 //   hi...      = c1.min.x, c1.max.x, c1.min.y, c1.max.y   (16-byte vector 1)
 //   zz         = c0.min.z, c0.max.z, c1.min.z, c1.max.z   (16-byte vector 2)
-//   child[0..1]: >= 0 inner-node index, < 0 : ~(3 * triangle slot), i.e. the complemented
+//   child[0..1]: >= 0 inner-node index, < 0 : ~(PT_TRI_RECORD_16B * triangle slot), i.e. the complemented
 //   position of the 48-byte record in 16-byte units;  child[2..3] unused
 struct WideNode {
     float c0xy[4];
@@ -69,10 +70,19 @@ struct TriRecord {
     float v2z; int32_t primid; int32_t pad[2];
 };
 static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
+// The record as the traversal arrays hold it: PT_TRI_RECORD_16B 16-byte units each.
+#if PT_TRI_RECORD_16B == 3
+using WideTriRecord = TriRecord;
+#else
+struct WideTriRecord : TriRecord {
+    int32_t tail[4 * (PT_TRI_RECORD_16B - 3)];
+};
+#endif
+static_assert(sizeof(WideTriRecord) == 16 * PT_TRI_RECORD_16B, "traversal triangle record size");
 
 struct WideBvh {
     std::vector<WideNode> nodes;
-    std::vector<TriRecord> tris;
+    std::vector<WideTriRecord> tris;
     uint32_t max_depth = 0;
 };
 

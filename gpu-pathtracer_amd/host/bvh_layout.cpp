@@ -168,7 +168,7 @@ void build_wide_layout(const BvhTree &t, const float *vtx, uint32_t n_vtx, const
     const uint32_t n_leaves = t.n_prims;
     const uint32_t n_inner = n_leaves > 1 ? n_leaves - 1 : 1;
     out.nodes.assign(n_inner, WideNode{});
-    out.tris.assign(n_leaves, TriRecord{});
+    out.tris.assign(n_leaves, WideTriRecord{});
     out.max_depth = 0;
 
     // Inner nodes and leaves are numbered separately, each in pre-order.
@@ -254,7 +254,7 @@ void build_wide_layout(const BvhTree &t, const float *vtx, uint32_t n_vtx, const
         w.cz[2 * c + 0] = b.pmin[2];
         w.cz[2 * c + 1] = b.pmax[2];
         // a leaf is named by the position of its record in 16-byte units, complemented
-        w.child[c] = slot[node] >= 0 ? slot[node] : ~(3 * ~slot[node]);
+        w.child[c] = slot[node] >= 0 ? slot[node] : ~(PT_TRI_RECORD_16B * ~slot[node]);
     };
 
     if (n == 1) {
@@ -266,9 +266,9 @@ void build_wide_layout(const BvhTree &t, const float *vtx, uint32_t n_vtx, const
         WideNode &w = out.nodes[0];
         set_child(w, 0, 0);
         set_child(w, 1, 0);
-        w.child[1] = ~3;
+        w.child[1] = ~PT_TRI_RECORD_16B;
         w.child[2] = w.child[3] = 0;
-        out.tris.assign(2, TriRecord{});
+        out.tris.assign(2, WideTriRecord{});
         fill_tri(0);
         TriRecord &r = out.tris[1];
         r = out.tris[0];

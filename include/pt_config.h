@@ -44,6 +44,11 @@
 #ifndef PT_TIE_BATCH
 #define PT_TIE_BATCH 16
 #endif
+/* Size of a traversal triangle record in 16-byte units: 3 (the 40 bytes in use, packed) or 4 (one
+ * record per 64 bytes, so that none lies across two of the 64-byte pieces memory is fetched in). */
+#ifndef PT_TRI_RECORD_16B
+#define PT_TRI_RECORD_16B 3
+#endif
 /* Threads per workgroup of the traversal kernels (a multiple of 64). */
 #ifndef PT_TRACE_BLOCK
 #define PT_TRACE_BLOCK 256
