@@ -72,6 +72,7 @@ ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bo
     c.spill_entries = ctx->stack_spill.ptr ? kSpillEntries : 0;
     c.max_grid = 0;
     c.xcd_slots = ctx->extend_xcd_slots > 0 ? 1 : 0;
+    c.quad = 0;
     // The LDS of a persistent workgroup (measured on MI355X: 262 K-triangle scene in the caches;
     // 10 M- and 28 M-triangle scenes beyond them, host-built trees of 32-36 levels and GPU-built
     // ones of 50-70):
@@ -102,6 +103,19 @@ ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bo
         } else {
             stack = 24; cache = 96;
         }
+    }
+    // Four-child nodes halve the node records a ray fetches and cost more arithmetic per record:
+    // for scenes whose records come from memory rather than from the caches (2^24 secondary rays,
+    // origin / queue order: 10 M triangles 9.1 / 13.1 -> 8.5 / 10.0 ms, 28 M triangles
+    // 12.3 / 13.8 -> 11.1 / 11.9 ms; the bench scene, in the caches, loses 7 %).  A step pushes up to
+    // three children, so the LDS goes to the stacks rather than to a copy of the top, and the
+    // rays in flight no longer need thinning out: five workgroups per compute unit again.
+    if (d.qnodes && !two_level && !d.big)
+        c.quad = ctx->extend_quad >= 0 ? (ctx->extend_quad ? 1 : 0) : (beyond_caches ? 1 : 0);
+    if (c.quad && beyond_caches) {
+        stack = coherent ? PT_LDS_STACK_ENTRIES : 24;
+        cache = coherent ? 0 : 96;
+        if (ctx->extend_blocks_per_cu <= 0) c.blocks_per_cu = 5;
     }
     c.stack_entries = ctx->extend_stack_entries > 0 ? ctx->extend_stack_entries : stack;
     c.cache_nodes = ctx->extend_cache_nodes >= 0 ? ctx->extend_cache_nodes : cache;
@@ -396,6 +410,11 @@ int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
         ctx->trace_sort_rays = (int)v;
     } else if (k == "extend.xcd_slots") {
         ctx->extend_xcd_slots = (int)v;
+    } else if (k == "extend.quad") {
+        if (v < -1 || v > 1) return fail(PT_ERR_INVALID, "extend.quad must be -1, 0 or 1");
+        ctx->extend_quad = (int)v;
+    } else if (k == "scene.quad") {
+        ctx->scene_quad = v != 0;
     } else if (k == "trace.sort_origin_bits") {
         if (v < 1 || v > 10) return fail(PT_ERR_INVALID, "trace.sort_origin_bits must be in [1,10]");
         ctx->sort_origin_bits = (int)v;
@@ -458,6 +477,52 @@ static int attach_top_cache(pt_context *ctx, pt_scene *sc) {
     sc->dev.top_cache = (const float4 *)buf;
     sc->dev.top_global = index;
     sc->dev.n_top_cache = n;
+    return PT_OK;
+}
+
+// The four-child form of the tree (DeviceScene::qnodes / qtris) and its LDS top, for scenes
+// whose records fit 32-bit byte offsets.  Costs 64 bytes per node and per leaf; a scene it cannot
+// be made for (a bound that is not finite, no memory) simply keeps the two-child form only.
+static int attach_quad(pt_context *ctx, pt_scene *sc) {
+    DeviceScene &d = sc->dev;
+    if (!ctx->scene_quad || d.n_wnodes < 1 || d.n_tri < 2 || d.big || d.tlas) return PT_OK;
+    const size_t n_leaves = (size_t)d.n_wnodes + 1;
+    if (needs_big_addresses(d.n_wnodes, n_leaves * 4 / PT_TRI_RECORD_16B + 1)) return PT_OK;
+    const size_t node_bytes = 64 * (size_t)d.n_wnodes, tri_bytes = 64 * n_leaves;
+    const size_t cache_bytes = 64 * (size_t)kNodeCacheMax, index_bytes = 4 * (size_t)kNodeCacheMax;
+    void *qn = nullptr, *qt = nullptr, *top = nullptr;
+    auto give_up = [&]() {
+        (void)hipGetLastError();
+        if (qn) (void)hipFree(qn);
+        if (qt) (void)hipFree(qt);
+        if (top) (void)hipFree(top);
+        return PT_OK;
+    };
+    if (hipMalloc(&qn, node_bytes) != hipSuccess) return give_up();
+    if (hipMalloc(&qt, tri_bytes) != hipSuccess) return give_up();
+    if (hipMalloc(&top, cache_bytes + index_bytes + 32) != hipSuccess) return give_up();
+    int32_t *index = reinterpret_cast<int32_t *>((char *)top + cache_bytes);
+    uint32_t *words = reinterpret_cast<uint32_t *>((char *)top + cache_bytes + index_bytes);   // n, bad
+    uint32_t host_words[2] = {0, 1};
+    hipError_t e = hipMemsetAsync(words, 0, 32, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(qt, 0, tri_bytes, ctx->stream);
+    if (e == hipSuccess) {
+        launch_build_quad(ctx->stream, d.wnodes, d.n_wnodes, d.wtris, d.n_tri, (float4 *)qn, (float4 *)qt,
+                          words + 1);
+        launch_build_quad_top_cache(ctx->stream, (const float4 *)qn, d.n_wnodes, (float4 *)top, index, words);
+        e = hipMemcpyAsync(host_words, words, 8, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess || host_words[1] != 0) return give_up();
+    sc->allocs.push_back(qn);
+    sc->allocs.push_back(qt);
+    sc->allocs.push_back(top);
+    d.qnodes = (const float4 *)qn;
+    d.qtris = (const float4 *)qt;
+    d.q_top_cache = (const float4 *)top;
+    d.q_top_global = index;
+    d.n_q_top_cache = host_words[0];
+    d.quad_depth = (d.wide_depth + 1) / 2;
     return PT_OK;
 }
 
@@ -610,6 +675,7 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     if (n_tri >= 2) {
         int rc = attach_top_cache(ctx, sc.get());
         if (rc == PT_OK) rc = attach_tri_leaf(ctx, sc.get());
+        if (rc == PT_OK) rc = attach_quad(ctx, sc.get());
         if (rc != PT_OK) return rc;
     }
     *out = sc.release();
@@ -744,6 +810,7 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
     {
         int rc = attach_top_cache(ctx, sc.get());
         if (rc == PT_OK) rc = attach_tri_leaf(ctx, sc.get());
+        if (rc == PT_OK) rc = attach_quad(ctx, sc.get());
         if (rc != PT_OK) return rc;
     }
     *out = sc.release();

@@ -39,6 +39,8 @@ struct pt_context {
     int extend_cache_nodes = -1;    // option "extend.cache_nodes" (-1: chosen per scene)
     int any_exact_order = 0;        // option "any.exact_order"
     int extend_xcd_slots = 0;       // option "extend.xcd_slots"
+    int extend_quad = -1;           // option "extend.quad": four-child nodes (-1: per scene)
+    bool scene_quad = true;         // option "scene.quad": scenes get the four-child form built
     int sort_origin_bits = 10;      // option "trace.sort_origin_bits"
     int sort_dir_bits = 0;          // option "trace.sort_dir_bits"
     int trace_sort_rays = -1;       // option "trace.sort_rays": 0 off, 1 on, -1 by scene size

@@ -56,6 +56,23 @@ struct DeviceScene {
     // each triangle's leaf (null otherwise).  Lets a ray with two near-equal candidates be
     // decided at those two leaves instead of by a walk over the whole tree.
     const int32_t *tri_leaf;
+    // Single-level scenes below 4 GiB of records: the same tree with two levels folded into one,
+    // as 64-byte four-child nodes whose child boxes are 8-bit offsets on a per-node grid (never
+    // inside the exact boxes), and 64-byte triangle records that carry the leaf's exact box.
+    //   qnodes[4 i .. 4 i + 3], i = index of the two-child node the record was folded from:
+    //     (origin.xyz, scale.x) (scale.y, scale.z, lo.x of 4 children, lo.y x4)
+    //     (lo.z x4, hi.x x4, hi.y x4, hi.z x4) (child 0..3)
+    //   a child is an index into qnodes (>= 0), ~(position of a qtris record in 16-byte units),
+    //   or kNoChild; child k's box is origin + byte k * scale per component.
+    //   qtris[4 j .. 4 j + 3]: (v0.xyz v1.x) (v1.yz v2.xy) (v2.z, triangle, lo.xy) (lo.z, hi.xyz)
+    // Half as many node records per ray, for more arithmetic per record: what pays once the
+    // records come from memory rather than from the caches.  Null when not built.
+    const float4 *qnodes;
+    const float4 *qtris;
+    const float4 *q_top_cache;      // as top_cache / top_global, over qnodes
+    const int32_t *q_top_global;
+    uint32_t n_q_top_cache;
+    uint32_t quad_depth;            // levels of four-child nodes
     // Optional: what a hit on each triangle reports as (shapeid, primid) from the stand-alone
     // closest-hit queries, the Face records of the reference's multi-mesh builder
     // (src/bvh/RadeonRays/intersector_skip_links.h:82-92).  Null: (0, triangle index).
@@ -74,6 +91,7 @@ struct DeviceScene {
 };
 
 constexpr int32_t kLdsNodeBase = 1 << 30;
+constexpr int32_t kNoChild = INT32_MIN;      // an unused child slot of a four-child node
 // What the child encodings can name: two-child nodes below kLdsNodeBase, triangle records by
 // their position in 16-byte units (three per record) in 31 bits.
 constexpr uint64_t kMaxWideNodes = (1ull << 30) - 1,
@@ -87,6 +105,15 @@ constexpr int kNodeCacheMax = PT_LDS_NODE_CACHE_MAX;
 // number of nodes to *n_out.
 void launch_build_top_cache(hipStream_t st, const float4 *wnodes, uint32_t n_wnodes, float4 *cache,
                             int32_t *global_index, uint32_t *n_out);
+// Folds the two-child nodes into four-child nodes with quantised child boxes and writes the
+// triangle records with their leaves' boxes (DeviceScene::qnodes / qtris, room for n_wnodes and
+// n_tri records of 64 bytes).  *bad becomes non-zero if some box does not quantise (a bound
+// that is not finite).
+void launch_build_quad(hipStream_t st, const float4 *wnodes, uint32_t n_wnodes, const float4 *wtris,
+                       uint32_t n_tri, float4 *qnodes, float4 *qtris, uint32_t *bad);
+// launch_build_top_cache over four-child nodes.
+void launch_build_quad_top_cache(hipStream_t st, const float4 *qnodes, uint32_t n_wnodes, float4 *cache,
+                                 int32_t *global_index, uint32_t *n_out);
 // Fills tri_leaf[0..n_tri) (preset to -1 by the caller) with the index of each triangle's leaf
 // among the n_nodes skip-link nodes; *multi becomes non-zero if some triangle has several.
 // Rewrites (shapeid, primid) of every hit record in hits[0..n) through face_ids.
@@ -133,6 +160,7 @@ struct ExtendConfig {
     int stack_entries;
     int cache_nodes;
     int xcd_slots;          // see PersistentParams
+    int quad;               // persistent closest-hit form: walk the four-child nodes (DeviceScene::qnodes)
     // persistent form: upper bound on the grid in workgroups (0: none), for a spill area that
     // was sized for fewer lanes than the device could keep resident
     unsigned int max_grid;
@@ -197,7 +225,8 @@ inline PersistentParams persistent_params(const ExtendConfig &cfg, const DeviceS
     pp.spill = cfg.spill;
     pp.spill_entries = cfg.spill_entries;
     pp.stack_cap = cfg.stack_entries;
-    pp.cache_nodes = s.tlas ? 0 : (int)(cfg.cache_nodes < (int)s.n_top_cache ? cfg.cache_nodes : s.n_top_cache);
+    const int top_nodes = (int)(cfg.quad ? s.n_q_top_cache : s.n_top_cache);
+    pp.cache_nodes = s.tlas ? 0 : (cfg.cache_nodes < top_nodes ? cfg.cache_nodes : top_nodes);
     if (pp.cache_nodes < 0) pp.cache_nodes = 0;
     pp.xcd_slots = cfg.xcd_slots;
     return pp;

@@ -238,6 +238,16 @@ __device__ __forceinline__ const float4 *wide_tri(const DeviceScene &s, int32_t 
                                             ((uint32_t)(~leaf) << 4));
 }
 
+// Records of the four-child form (scenes below 4 GiB of records only: 32-bit byte offsets).
+__device__ __forceinline__ const float4 *quad_node(const DeviceScene &s, int32_t node) {
+    return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.qnodes) +
+                                            ((uint32_t)node << 6));
+}
+__device__ __forceinline__ const float4 *quad_tri(const DeviceScene &s, int32_t leaf) {
+    return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.qtris) +
+                                            ((uint32_t)(~leaf) << 4));
+}
+
 // Ordered closest-hit traversal of one ray.  `stack` points at this lane's column of the
 // workgroup's LDS stack (entry e at stack[e * kTraceBlock]).  Sets `tie` when the result
 // could depend on the visiting order; the caller then re-resolves the ray with
@@ -431,7 +441,12 @@ __device__ __forceinline__ void any_begin(OrderedState &st, const float4 ro, con
 // only divergent regions are the stack accesses and the work inside the triangle test.
 // ANY: occlusion query -- the triangle step is the Moller-Trumbore test of
 // shaders/RadeonRays/bvh.glslh:289-310 and the first hit ends the ray.
-template <bool COUNT, bool ANY = false, bool CACHE = false, bool BIG = false>
+// QUAD: the node step reads a four-child node (DeviceScene::qnodes): child boxes from 8-bit
+// offsets on the node's grid, never inside the exact boxes, so a ray that reaches a leaf in the
+// two-child tree reaches it here too; the slab arithmetic on them is the reference's (rounding
+// is monotonic in the box).  The leaf's exact box, the one the reference tests, comes with the
+// triangle record and is tested at the triangle step, against the nearest hit at that time.
+template <bool COUNT, bool ANY = false, bool CACHE = false, bool BIG = false, bool QUAD = false>
 __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedState &st,
                                                 int32_t *stack, int min_active, int leaf_lanes,
                                                 unsigned long long &nb, unsigned long long &nt,
@@ -452,6 +467,74 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
         bool at_node, at_leaf;
         int mode = vote(at_node, at_leaf);
         while (mode == 0) {
+            if constexpr (QUAD) {
+              if (at_node) {
+                static_assert(!(QUAD && (ANY || BIG)), "four-child nodes: closest hits, 32-bit offsets");
+                float4 f0, f1, f2;
+                int4 ch;
+                if (CACHE && st.cur >= kLdsNodeBase) {
+                    const LdsFloat4 *np = cache + ((st.cur - kLdsNodeBase) << 2);
+                    f0 = lds_load4(np); f1 = lds_load4(np + 1); f2 = lds_load4(np + 2);
+                    const float4 cw = lds_load4(np + 3);
+                    ch = make_int4(__float_as_int(cw.x), __float_as_int(cw.y), __float_as_int(cw.z),
+                                   __float_as_int(cw.w));
+                    if (COUNT && nl) *nl += 4;
+                } else {
+                    const float4 *np = quad_node(s, st.cur);
+                    f0 = np[0]; f1 = np[1]; f2 = np[2];
+                    ch = reinterpret_cast<const int4 *>(np)[3];
+                }
+                if (COUNT) nb += 4;
+                const uint32_t qlx = __float_as_uint(f1.z), qly = __float_as_uint(f1.w),
+                               qlz = __float_as_uint(f2.x), qhx = __float_as_uint(f2.y),
+                               qhy = __float_as_uint(f2.z), qhz = __float_as_uint(f2.w);
+                float key[4];
+                int32_t ref[4] = {ch.x, ch.y, ch.z, ch.w};
+                int nh = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lx = __builtin_fmaf((float)((qlx >> (8 * k)) & 0xffu), f0.w, f0.x);
+                    const float ly = __builtin_fmaf((float)((qly >> (8 * k)) & 0xffu), f1.x, f0.y);
+                    const float lz = __builtin_fmaf((float)((qlz >> (8 * k)) & 0xffu), f1.y, f0.z);
+                    const float hx = __builtin_fmaf((float)((qhx >> (8 * k)) & 0xffu), f0.w, f0.x);
+                    const float hy = __builtin_fmaf((float)((qhy >> (8 * k)) & 0xffu), f1.x, f0.y);
+                    const float hz = __builtin_fmaf((float)((qhz >> (8 * k)) & 0xffu), f1.y, f0.z);
+                    float t;
+                    const bool h = intersect_box(st.r, lx, hx, ly, hy, lz, hz, st.bound, t) &&
+                                   ref[k] != kNoChild;
+                    key[k] = h ? fminf(t, 3.0e38f) : INFINITY;
+                    nh += h ? 1 : 0;
+                }
+                // children in order of entry distance (misses last): five compare-exchanges
+#define PT_CE(a, b)                                                        \
+    {                                                                      \
+        const bool sw = key[b] < key[a];                                   \
+        const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];  \
+        const int32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];\
+        key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb;                \
+    }
+                PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#undef PT_CE
+                // No room for the farther children: as in the two-child step, the lane stops with
+                // the node itself on top of its stack.
+                const bool full = nh > 1 && st.sp + nh - 1 > stack_cap;
+                int32_t next = ref[0];
+                if (full) {
+                    stack[st.sp * kTraceBlock] = st.cur;
+                    ++st.sp;
+                    next = kSentinel;
+                } else if (nh > 1) {
+                    if (nh > 3) { stack[st.sp * kTraceBlock] = ref[3]; ++st.sp; }
+                    if (nh > 2) { stack[st.sp * kTraceBlock] = ref[2]; ++st.sp; }
+                    stack[st.sp * kTraceBlock] = ref[1];
+                    ++st.sp;
+                } else if (nh == 0) {
+                    --st.sp;
+                    next = stack[st.sp * kTraceBlock];
+                }
+                st.cur = next;
+              }
+            } else
             if (at_node) {
                 float4 a, b, c;
                 int2 ch;                                    // the two children: 8 of the last 16 bytes
@@ -495,12 +578,21 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
         }
         if (mode == 2) return;
         if (at_leaf) {
-            const float4 *tp = wide_tri<BIG>(s, st.cur);
+            const float4 *tp = QUAD ? quad_tri(s, st.cur) : wide_tri<BIG>(s, st.cur);
             const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+            bool in_leaf_box = true;
+            if constexpr (QUAD) {
+                // the leaf's own box, the one test of the reference's that the coarse boxes on the
+                // way here stand in for
+                const float4 q3 = tp[3];
+                float t;
+                in_leaf_box = intersect_box(st.r, q2.z, q3.y, q2.w, q3.z, q3.x, q3.w, st.bound, t);
+                if (COUNT) ++nb;
+            }
 #ifdef PT_WAVE_ITERS
             if (COUNT && (__ffsll(__ballot(1)) - 1) == (int)(threadIdx.x & 63)) nt += 64;
 #else
-            if (COUNT) ++nt;
+            if (COUNT) nt += in_leaf_box ? 1 : 0;
 #endif
             if (ANY) {
                 float m1, m2, temp;
@@ -517,7 +609,8 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
             }
             float h0 = 0.f, h1 = 0.f, h2 = 0.f, ht = 0.f;
             const bool hit = intersect_triangle_watertight(st.r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y,
-                                                           q1.z, q1.w, q2.x, st.bound, h0, h1, h2, ht);
+                                                           q1.z, q1.w, q2.x, st.bound, h0, h1, h2, ht) &
+                             in_leaf_box;
             const bool bad = hit & !(ht == ht);
             const bool had = st.primid >= 0;
             const bool closer = hit & !bad & (!had | (ht < st.tbest));
@@ -857,7 +950,7 @@ struct HitSink {
 // drains.  ANY = false: closest hits, sink(ray, shapeid, primid, b0, b1, b2, t).
 // ANY = true: occlusion queries, sink(ray, occluded).  perm, if not null, is the order in
 // which to take the rays (queue position -> ray index); sinks always get the ray index.
-template <bool COUNT, bool ANY, bool CACHE, bool BIG, class Sink>
+template <bool COUNT, bool ANY, bool CACHE, bool BIG, class Sink, bool QUAD = false>
 __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const pt_ray *rays,
                                                     uint32_t n, bool fixup, const PersistentParams pp,
                                                     unsigned int *tie_count,
@@ -872,15 +965,24 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     LdsFloat4 *const cache = CACHE ? persistent_cache(stack_cap) : nullptr;
     int32_t root = 0;
     if (CACHE) {
-        const uint32_t n_cached = min((uint32_t)pp.cache_nodes, s.n_top_cache);
+        const float4 *const top = QUAD ? s.q_top_cache : s.top_cache;
+        const int32_t *const top_global = QUAD ? s.q_top_global : s.top_global;
+        const uint32_t n_cached = min((uint32_t)pp.cache_nodes, QUAD ? s.n_q_top_cache : s.n_top_cache);
         for (uint32_t i = threadIdx.x; i < 4u * n_cached; i += kTraceBlock) {
-            float4 v = s.top_cache[i];
+            float4 v = top[i];
             if ((i & 3u) == 3u) {
                 int32_t c0 = __float_as_int(v.x), c1 = __float_as_int(v.y);
-                if (c0 >= kLdsNodeBase + (int32_t)n_cached) c0 = s.top_global[c0 - kLdsNodeBase];
-                if (c1 >= kLdsNodeBase + (int32_t)n_cached) c1 = s.top_global[c1 - kLdsNodeBase];
+                if (c0 >= kLdsNodeBase + (int32_t)n_cached) c0 = top_global[c0 - kLdsNodeBase];
+                if (c1 >= kLdsNodeBase + (int32_t)n_cached) c1 = top_global[c1 - kLdsNodeBase];
                 v.x = __int_as_float(c0);
                 v.y = __int_as_float(c1);
+                if constexpr (QUAD) {
+                    int32_t c2 = __float_as_int(v.z), c3 = __float_as_int(v.w);
+                    if (c2 >= kLdsNodeBase + (int32_t)n_cached) c2 = top_global[c2 - kLdsNodeBase];
+                    if (c3 >= kLdsNodeBase + (int32_t)n_cached) c3 = top_global[c3 - kLdsNodeBase];
+                    v.z = __int_as_float(c2);
+                    v.w = __int_as_float(c3);
+                }
             }
             lds_store4(cache + i, v);
         }
@@ -1047,7 +1149,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
             if (pos >= stream_len) break;
             continue;                                           // tail positions past the queue end
         }
-        ordered_advance<COUNT, ANY, CACHE, BIG>(s, st, stack, pos < stream_len ? 64 - refill : 0,
+        ordered_advance<COUNT, ANY, CACHE, BIG, QUAD>(s, st, stack, pos < stream_len ? 64 - refill : 0,
                                                 leaf_lanes, nb, nt, stack_cap, cache, &nl);
     }
     if constexpr (!ANY) walk_parked();
@@ -1353,14 +1455,15 @@ __device__ __forceinline__ void persistent_traverse_two_level(
     }
 }
 
-template <bool COUNT, bool CACHE, bool BIG>
+template <bool COUNT, bool CACHE, bool BIG, bool QUAD = false>
 __device__ __forceinline__ void persistent_closest_hits(const DeviceScene &s, const pt_ray *rays,
                                                         pt_hit *hits, uint32_t n, bool fixup,
                                                         const PersistentParams pp,
                                                         unsigned int *tie_count,
                                                         DeviceTraceCounters *work,
                                                         const uint32_t *perm = nullptr) {
-    persistent_traverse<COUNT, false, CACHE, BIG>(s, rays, n, fixup, pp, tie_count, work, HitSink{hits}, perm);
+    persistent_traverse<COUNT, false, CACHE, BIG, HitSink, QUAD>(s, rays, n, fixup, pp, tie_count, work,
+                                                                HitSink{hits}, perm);
 }
 
 // Compacting append to a queue: every lane with `keep` gets a distinct slot.  One atomic

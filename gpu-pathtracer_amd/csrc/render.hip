@@ -136,11 +136,11 @@ __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_two_l
 // static, so no work-distribution atomics), and a wave tops its idle lanes up from its own
 // stream whenever `refill` or more of them have finished, instead of idling them until its
 // slowest ray ends.
-template <bool COUNT, bool CACHE, bool BIG>
+template <bool COUNT, bool CACHE, bool BIG, bool QUAD = false>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, const unsigned int *count,
     unsigned int *tie_count, DeviceTraceCounters *work, PersistentParams pp) {
-    persistent_closest_hits<COUNT, CACHE, BIG>(s, rays, hits, *count, true, pp, tie_count, work);
+    persistent_closest_hits<COUNT, CACHE, BIG, QUAD>(s, rays, hits, *count, true, pp, tie_count, work);
 }
 
 // shade: one path vertex per queued hit; survivors are appended to the next queue.
@@ -379,7 +379,13 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
             k_pt_extend_persistent<false, true, false>,  k_pt_extend_persistent<false, true, true>,
             k_pt_extend_persistent<true, false, false>,  k_pt_extend_persistent<true, false, true>,
             k_pt_extend_persistent<true, true, false>,   k_pt_extend_persistent<true, true, true>};
-        const K k = table[(work ? 4 : 0) | (pp.cache_nodes > 0 ? 2 : 0) | (s.big ? 1 : 0)];
+        // the same over the four-child nodes (scenes that have them; never with 64-bit addresses)
+        static const K quad_table[4] = {
+            k_pt_extend_persistent<false, false, false, true>, k_pt_extend_persistent<false, true, false, true>,
+            k_pt_extend_persistent<true, false, false, true>,  k_pt_extend_persistent<true, true, false, true>};
+        const bool quad = cfg.quad && s.qnodes && !s.big;
+        const K k = quad ? quad_table[(work ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)]
+                         : table[(work ? 4 : 0) | (pp.cache_nodes > 0 ? 2 : 0) | (s.big ? 1 : 0)];
         launch_persistent(k, st, blocks(max_rays, kBlock), cfg, pp, s, (const pt_ray *)ws.rays[buf], ws.hits, count,
                           tie_count, work, pp);
         return;

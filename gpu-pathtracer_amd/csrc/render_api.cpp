@@ -278,6 +278,17 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
     }
     // a pass's queues are in pixel order: neighbouring rays start next to each other
     const ExtendConfig ecfg = make_extend_config(ctx, scene, true);
+    // Camera rays and the first bounce are coherent enough for the caches to serve the two-child
+    // nodes, which cost less arithmetic; from the second bounce on the four-child nodes pay
+    // where the scene has them and the policy picked them (4K, 10 M triangles, depth 8: 42.3 ms of
+    // extend with two-child nodes throughout, 36.3 with four-child nodes throughout, of which the
+    // first two launches take 19.0 instead of 17.8).
+    ExtendConfig ecfg_first = ecfg;
+    if (ctx->extend_quad < 0 && ecfg.quad) {
+        ecfg_first.quad = 0;
+        ecfg_first.stack_entries = ctx->extend_stack_entries > 0 ? ctx->extend_stack_entries : 24;
+        ecfg_first.cache_nodes = ctx->extend_cache_nodes >= 0 ? ctx->extend_cache_nodes : 96;
+    }
     // Kernel timing: one event between every two launches of the call; the span between two
     // neighbouring events is the device time of the launch recorded between them.
     const bool timing = ctx->kernel_timing;
@@ -311,7 +322,8 @@ int pt_render(pt_context *ctx, const pt_scene *scene, const pt_camera *cam,
         PT_TIMED(kRaygen, launch_pt_raygen(st, rl, ws, &c[0]));
         int buf = 0;
         for (uint32_t b = 0; b < p.max_depth; ++b) {
-            PT_TIMED(kExtend, launch_pt_extend(st, scene->dev, ws, buf, &c[b], paths, tie_count, work, ecfg));
+            PT_TIMED(kExtend, launch_pt_extend(st, scene->dev, ws, buf, &c[b], paths, tie_count, work,
+                                               b < 2 ? ecfg_first : ecfg));
             if (depth_mode) {
                 PT_TIMED(kShade, launch_pt_shade_depth(st, ws, &c[b], paths));
             } else {

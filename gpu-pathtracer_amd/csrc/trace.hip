@@ -71,11 +71,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_ordered(DeviceScene s, const p
     }
 }
 
-template <bool COUNT, bool CACHE, bool BIG>
+template <bool COUNT, bool CACHE, bool BIG, bool QUAD = false>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_ordered_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, uint32_t n, bool fixup, PersistentParams pp,
     DeviceTraceCounters *counters, const uint32_t *perm) {
-    persistent_closest_hits<COUNT, CACHE, BIG>(s, rays, hits, n, fixup, pp, &counters->tie_count, counters, perm);
+    persistent_closest_hits<COUNT, CACHE, BIG, QUAD>(s, rays, hits, n, fixup, pp, &counters->tie_count,
+                                                     counters, perm);
 }
 
 // IntersectSceneAny, shaders/RadeonRays/bvh.glslh:378-414 (leaf test :350-375, :289-310).
@@ -243,9 +244,137 @@ __global__ void k_build_top_cache(const float4 *wnodes, uint32_t n_wnodes, float
     *n_out = (uint32_t)count;
 }
 
+// Four-child nodes from the two-child ones, one thread per two-child node i: the children of
+// record i are i's grandchildren (a child of i that is a leaf stays a child), so a traversal
+// from record 0 only ever reaches the records of even depth; the others are built all the same,
+// which keeps this a single independent pass with the numbering -- and so the locality in
+// memory -- of the two-child array.  A child's box is stored as 8-bit steps of a per-node grid,
+// rounded outwards with the very fused multiply-add the traversal decodes it with, so the
+// decoded box never lies inside the exact one.
+__device__ __forceinline__ int32_t quad_leaf_ref(int32_t wide_leaf) {      // ~(16-byte position)
+    return ~(int32_t)(4u * ((uint32_t)(~wide_leaf) / (uint32_t)PT_TRI_RECORD_16B));
+}
+__global__ __launch_bounds__(256) void k_build_quad(const float4 *wnodes, uint32_t n_wnodes,
+                                                    const float4 *wtris, float4 *qnodes,
+                                                    float4 *qtris, uint32_t *bad) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_wnodes) return;
+    float lo[4][3], hi[4][3];
+    int32_t ref[4] = {kNoChild, kNoChild, kNoChild, kNoChild};
+    int m = 0;
+    auto child_box = [](const float4 *np, int c, float *l, float *h) {
+        const float4 xy = np[c], z = np[2];
+        l[0] = xy.x; h[0] = xy.y; l[1] = xy.z; h[1] = xy.w;
+        l[2] = c ? z.z : z.x; h[2] = c ? z.w : z.y;
+    };
+    const float4 *np = wnodes + 4 * (size_t)i;
+    const int4 ch = reinterpret_cast<const int4 *>(np)[3];
+    const int32_t c2[2] = {ch.x, ch.y};
+    for (int c = 0; c < 2; ++c) {
+        if (c2[c] < 0) {                               // a leaf: stays a child, and its record is made
+            child_box(np, c, lo[m], hi[m]);
+            ref[m] = quad_leaf_ref(c2[c]);
+            const float4 *src = wtris + (size_t)(uint32_t)(~c2[c]);
+            float4 *dst = qtris + (size_t)(uint32_t)(~ref[m]);
+            const float4 s2 = src[2];
+            dst[0] = src[0];
+            dst[1] = src[1];
+            dst[2] = make_float4(s2.x, s2.y, lo[m][0], lo[m][1]);
+            dst[3] = make_float4(lo[m][2], hi[m][0], hi[m][1], hi[m][2]);
+            ++m;
+        } else {
+            const float4 *gp = wnodes + 4 * (size_t)c2[c];
+            const int4 gch = reinterpret_cast<const int4 *>(gp)[3];
+            const int32_t g2[2] = {gch.x, gch.y};
+            for (int g = 0; g < 2; ++g) {
+                child_box(gp, g, lo[m], hi[m]);
+                ref[m] = g2[g] >= 0 ? g2[g] : quad_leaf_ref(g2[g]);
+                ++m;
+            }
+        }
+    }
+    float org[3], scale[3];
+    uint32_t ql[3] = {0, 0, 0}, qh[3] = {0, 0, 0};
+    bool ok = true;
+    for (int a = 0; a < 3; ++a) {
+        float mn = lo[0][a], mx = hi[0][a];
+        for (int k = 1; k < m; ++k) {
+            mn = fminf(mn, lo[k][a]);
+            mx = fmaxf(mx, hi[k][a]);
+        }
+        org[a] = mn;
+        float sc = (mx - mn) / 255.0f;
+        ok &= (fabsf(mn) < INFINITY) & (fabsf(mx) < INFINITY) & (sc == sc) & (sc < INFINITY);
+        if (ok)
+            for (int guard = 0; guard < 64 && __builtin_fmaf(255.0f, sc, mn) < mx; ++guard)
+                sc = __uint_as_float(__float_as_uint(sc) + 1u);        // next float up (sc >= 0)
+        ok &= !(__builtin_fmaf(255.0f, sc, mn) < mx);
+        scale[a] = sc;
+        for (int k = 0; k < m && ok; ++k) {
+            int q = sc > 0.f ? (int)fminf(fmaxf(floorf((lo[k][a] - mn) / sc), 0.f), 255.f) : 0;
+            while (q > 0 && __builtin_fmaf((float)q, sc, mn) > lo[k][a]) --q;
+            while (q < 255 && __builtin_fmaf((float)(q + 1), sc, mn) <= lo[k][a]) ++q;
+            ok &= !(__builtin_fmaf((float)q, sc, mn) > lo[k][a]);
+            ql[a] |= (uint32_t)q << (8 * k);
+            int r = sc > 0.f ? (int)fminf(fmaxf(ceilf((hi[k][a] - mn) / sc), 0.f), 255.f) : 0;
+            while (r < 255 && __builtin_fmaf((float)r, sc, mn) < hi[k][a]) ++r;
+            while (r > 0 && __builtin_fmaf((float)(r - 1), sc, mn) >= hi[k][a]) --r;
+            ok &= !(__builtin_fmaf((float)r, sc, mn) < hi[k][a]);
+            qh[a] |= (uint32_t)r << (8 * k);
+        }
+    }
+    if (!ok) atomicOr(bad, 1u);
+    float4 *q = qnodes + 4 * (size_t)i;
+    q[0] = make_float4(org[0], org[1], org[2], scale[0]);
+    q[1] = make_float4(scale[1], scale[2], __uint_as_float(ql[0]), __uint_as_float(ql[1]));
+    q[2] = make_float4(__uint_as_float(ql[2]), __uint_as_float(qh[0]), __uint_as_float(qh[1]),
+                       __uint_as_float(qh[2]));
+    reinterpret_cast<int4 *>(q)[3] = make_int4(ref[0], ref[1], ref[2], ref[3]);
+}
+
+// k_build_top_cache over the four-child nodes.
+__global__ void k_build_quad_top_cache(const float4 *qnodes, uint32_t n_nodes, float4 *cache,
+                                       int32_t *queue, uint32_t *n_out, int capacity) {
+    if (blockIdx.x || threadIdx.x) return;
+    int count = 0;
+    if (n_nodes > 0 && capacity > 0) {
+        queue[0] = 0;
+        count = 1;
+        for (int i = 0; i < count; ++i) {
+            const float4 *np = qnodes + 4 * (size_t)queue[i];
+            const int4 ch = reinterpret_cast<const int4 *>(np)[3];
+            int32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
+            for (int k = 0; k < 4; ++k)
+                if (c[k] >= 0 && count < capacity) {
+                    queue[count] = c[k];
+                    c[k] = kLdsNodeBase + count;
+                    ++count;
+                }
+            cache[4 * i + 0] = np[0];
+            cache[4 * i + 1] = np[1];
+            cache[4 * i + 2] = np[2];
+            reinterpret_cast<int4 *>(cache)[4 * i + 3] = make_int4(c[0], c[1], c[2], c[3]);
+        }
+    }
+    *n_out = (uint32_t)count;
+}
+
 inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kBlock - 1) / kBlock); }
 
 } // namespace
+
+void launch_build_quad(hipStream_t st, const float4 *wnodes, uint32_t n_wnodes, const float4 *wtris,
+                       uint32_t n_tri, float4 *qnodes, float4 *qtris, uint32_t *bad) {
+    (void)n_tri;
+    hipLaunchKernelGGL(k_build_quad, dim3((n_wnodes + 255u) / 256u), dim3(256), 0, st, wnodes, n_wnodes,
+                       wtris, qnodes, qtris, bad);
+}
+
+void launch_build_quad_top_cache(hipStream_t st, const float4 *qnodes, uint32_t n_wnodes, float4 *cache,
+                                 int32_t *global_index, uint32_t *n_out) {
+    hipLaunchKernelGGL(k_build_quad_top_cache, dim3(1), dim3(1), 0, st, qnodes, n_wnodes, cache,
+                       global_index, n_out, (int)kNodeCacheMax);
+}
 
 void launch_build_top_cache(hipStream_t st, const float4 *wnodes, uint32_t n_wnodes, float4 *cache,
                             int32_t *global_index, uint32_t *n_out) {
@@ -398,7 +527,13 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
             k_trace_ordered_persistent<false, true, false>,  k_trace_ordered_persistent<false, true, true>,
             k_trace_ordered_persistent<true, false, false>,  k_trace_ordered_persistent<true, false, true>,
             k_trace_ordered_persistent<true, true, false>,   k_trace_ordered_persistent<true, true, true>};
-        const K k = table[(count_work ? 4 : 0) | (cached ? 2 : 0) | (s.big ? 1 : 0)];
+        // the same over the four-child nodes (scenes that have them; never with 64-bit addresses)
+        static const K quad_table[4] = {
+            k_trace_ordered_persistent<false, false, false, true>, k_trace_ordered_persistent<false, true, false, true>,
+            k_trace_ordered_persistent<true, false, false, true>,  k_trace_ordered_persistent<true, true, false, true>};
+        const bool quad = cfg.quad && s.qnodes && !s.big;
+        const K k = quad ? quad_table[(count_work ? 2 : 0) | (cached ? 1 : 0)]
+                         : table[(count_work ? 4 : 0) | (cached ? 2 : 0) | (s.big ? 1 : 0)];
         if (bracket) (void)hipEventRecord(bracket[0], st);
         launch_persistent(k, st, grid_for(n), cfg, pp, s, rays, hits, (uint32_t)n, fixup, pp, counters, perm);
         if (bracket) (void)hipEventRecord(bracket[1], st);

@@ -44,6 +44,16 @@ def _compare(mipt, oracle, ctx, scene, cam, W, H, exact=True, **kw):
               f"{st.tie_rays} ties")
         if exact:
             assert n_diff == 0, f"film differs from the CPU restatement in {n_diff} words"
+            # the extend kernel over the four-child nodes (forced for every bounce): the same film
+            ctx.set_option("extend.quad", 1)
+            try:
+                film.clear()
+                mipt.render(ctx, sc, cam, p, film)
+                quad = film.read()
+            finally:
+                ctx.set_option("extend.quad", -1)
+            nq = int((quad.view(np.uint32) != want.view(np.uint32)).sum())
+            assert nq == 0, f"film over four-child nodes differs from the CPU restatement in {nq} words"
         return got, st
     finally:
         film.close()

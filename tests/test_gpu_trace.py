@@ -32,6 +32,16 @@ def _check_all_modes(mipt, oracle, ctx, nodes, vtx, idx, rays, expect_ties=None,
         assert st.rays == len(rays)
         if expect_ties is not None:
             assert expect_ties(st.tie_rays), f"tie_rays = {st.tie_rays}"
+        # the same tree as four-child nodes with quantised boxes (what scenes beyond the caches
+        # are walked by): every record the same again
+        ctx.set_option("extend.quad", 1)
+        try:
+            quad, stq = sc.trace_closest(rays, mipt.PT_TRACE_DEFAULT, stats=True)
+        finally:
+            ctx.set_option("extend.quad", -1)
+        bad = same_hits(quad, want, nan_equal)
+        assert len(bad) == 0, (f"four-child traversal differs from the oracle on {len(bad)} of "
+                               f"{len(rays)} rays, first {bad[:8]}: {quad[bad[:3]]} vs {want[bad[:3]]}")
         return got, st
     finally:
         sc.close()

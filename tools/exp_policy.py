@@ -12,7 +12,11 @@ from mipt import scenes
 ctx = mipt.Context(0)
 ctx.set_kernel_timing(True)
 splits = os.environ.get("SPLITS", "-1:-1:-1 16:224:5 24:96:5 30:128:4 30:128:5").split()
-which = sys.argv[1:] or ["clutter10m", "sphere28m"]
+which = [a for a in sys.argv[1:] if "=" not in a] or ["clutter10m", "sphere28m"]
+for a in sys.argv[1:]:                      # key=int: pt_context_set_option first
+    if "=" in a:
+        k_, _, v_ = a.partition("=")
+        ctx.set_option(k_, int(v_))
 for name in which:
     if name == "clutter10m":
         vtx, idx, mats, mids = scenes.clutter(10_000_000, seed=11)
