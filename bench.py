@@ -393,7 +393,9 @@ def hbm_record(args, ctx, torch, mipt, scenes):
     sc.close()
     best = res["origin_cell_order"]
     ach = bpr * n / (best["kernel_ms"] * 1e-3) / 1e9
-    rec = {"bound": "hbm", "kernel": "k_trace_ordered_persistent<false>",
+    rec = {"bound": "hbm",
+           "kernel": "k_trace_ordered_persistent (four-child nodes with quantised boxes: the form "
+                     "scenes beyond the caches are walked in; slab tests counted per child box)",
            "workload": "Lucy-class displaced closed surface, %d tris (%.2f GB of node + triangle records), "
                        "%d secondary rays (origins on the surface, cosine directions, seed 7), tree built "
                        "on the GPU with 8 optimisation passes in %.2f s" %

@@ -215,7 +215,13 @@ int pt_context_last_trace_ms(pt_context *ctx, double *ms);
  * rays that need more go on in global memory) and a copy of the first nodes of the tree,
  * breadth first from the root, which the steps every ray takes first then read from LDS
  * instead of through the vector memory pipeline (default -1: 16 entries + 224 nodes for trees
- * up to 40 levels deep, 30 entries and no copy for deeper ones; single-level scenes only);
+ * up to 40 levels deep that fit the 256 MB Infinity Cache, 24 + 96 for deeper or larger ones;
+ * single-level scenes only);
+ * "extend.quad" -1|0|1: closest hits walk the tree as 64-byte four-child nodes with 8-bit child
+ * boxes and exact leaf boxes beside the triangles -- half the records per ray for more
+ * arithmetic per record (default -1: trace calls on scenes beyond the Infinity Cache, render
+ * passes on such scenes from the second bounce on); "scene.quad" 1|0: scenes created from now
+ * on get that form built (64 bytes per node and per triangle; default 1);
  * "any.exact_order" 0|1: occlusion queries walk the reference's skip links
  * instead of the two-child nodes (default 0); "trace.sort_rays" -1|0|1: pt_trace_closest*
  * takes the rays in Morton order of their origins (default -1: when the scene exceeds the

@@ -76,7 +76,10 @@ for key in sorted(per_launch):
         lines.append("    %-40s per launch %.6g" % (counter, v))
 with open(os.path.join(here, "r02_pmc_summary.txt"), "w") as f:
     f.write("rocprofv3 --pmc, one counter group per run of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`;\n"
-            "values are means per launch of the kernel (summed over XCDs / channels as rocprofv3 reports them)\n")
+            "values are means per launch of the kernel (summed over XCDs / channels as rocprofv3 reports them).\n"
+            "k_trace_ordered_persistent<counting, LDS copy of the top, 64-bit addresses, four-child nodes>: on the\n"
+            "28 M-triangle scene <false, false, false, true> traces the rays in origin-cell order and\n"
+            "<false, true, false, true> the same rays in queue order (four launches each).\n")
     f.write("\n".join(lines) + "\n")
 
 
@@ -114,6 +117,11 @@ for fname, prefix, label, rays in (
          bench["config"]["rays_per_step_per_gpu"] * bench["steps"] / bench["roofline"]["launches"]),
         ("r02_traffic_hbm.json", "k_trace_ordered_persistent<false", " [origin-cell order]", float(1 << 24))):
     keys = [k for k in per_launch if k.startswith(prefix) and k.endswith(label or ">")]
+    if not keys and label:
+        # four-child nodes: the rays in origin-cell order are traced by the variant without the
+        # LDS copy of the top (template arguments <counting, cached, 64-bit, four-child>), the
+        # rays in queue order by the one with it -- two kernels of four launches each
+        keys = [k for k in per_launch if k.startswith("k_trace_ordered_persistent<false, false, false, true>")]
     if not keys:
         print("no launches of", prefix)
         continue
