@@ -491,18 +491,34 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                 float key[4];
                 int32_t ref[4] = {ch.x, ch.y, ch.z, ch.w};
                 int nh = 0;
+                // The slab test of bvh.glslh:165-177 on the decoded boxes, with the min / max of
+                // the two planes of an axis taken by the sign of 1/d instead (one select per axis
+                // for the four children together): the same numbers wherever no product is a NaN
+                // (a decoded lo is never above its hi, and rounding is monotonic), and where one is
+                // (a ray inside a box plane with no extent along that axis) the plane drops out
+                // of the max3 / min3 -- which can only let the ray into a coarse box the
+                // reference's arithmetic would have kept it out of.  Not so for a leaf's exact
+                // box, whose test is the reference's as written (triangle step).
+                const bool sgx = __float_as_int(st.r.ix) < 0, sgy = __float_as_int(st.r.iy) < 0,
+                           sgz = __float_as_int(st.r.iz) < 0;
+                const uint32_t qnx = sgx ? qhx : qlx, qfx = sgx ? qlx : qhx;
+                const uint32_t qny = sgy ? qhy : qly, qfy = sgy ? qly : qhy;
+                const uint32_t qnz = sgz ? qhz : qlz, qfz = sgz ? qlz : qhz;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float lx = __builtin_fmaf((float)((qlx >> (8 * k)) & 0xffu), f0.w, f0.x);
-                    const float ly = __builtin_fmaf((float)((qly >> (8 * k)) & 0xffu), f1.x, f0.y);
-                    const float lz = __builtin_fmaf((float)((qlz >> (8 * k)) & 0xffu), f1.y, f0.z);
-                    const float hx = __builtin_fmaf((float)((qhx >> (8 * k)) & 0xffu), f0.w, f0.x);
-                    const float hy = __builtin_fmaf((float)((qhy >> (8 * k)) & 0xffu), f1.x, f0.y);
-                    const float hz = __builtin_fmaf((float)((qhz >> (8 * k)) & 0xffu), f1.y, f0.z);
-                    float t;
-                    const bool h = intersect_box(st.r, lx, hx, ly, hy, lz, hz, st.bound, t) &&
-                                   ref[k] != kNoChild;
-                    key[k] = h ? fminf(t, 3.0e38f) : INFINITY;
+                    const float pnx = __builtin_fmaf((float)((qnx >> (8 * k)) & 0xffu), f0.w, f0.x);
+                    const float pny = __builtin_fmaf((float)((qny >> (8 * k)) & 0xffu), f1.x, f0.y);
+                    const float pnz = __builtin_fmaf((float)((qnz >> (8 * k)) & 0xffu), f1.y, f0.z);
+                    const float pfx = __builtin_fmaf((float)((qfx >> (8 * k)) & 0xffu), f0.w, f0.x);
+                    const float pfy = __builtin_fmaf((float)((qfy >> (8 * k)) & 0xffu), f1.x, f0.y);
+                    const float pfz = __builtin_fmaf((float)((qfz >> (8 * k)) & 0xffu), f1.y, f0.z);
+                    const float nx = (pnx - st.r.ox) * st.r.ix, fx = (pfx - st.r.ox) * st.r.ix;
+                    const float ny = (pny - st.r.oy) * st.r.iy, fy = (pfy - st.r.oy) * st.r.iy;
+                    const float nz = (pnz - st.r.oz) * st.r.iz, fz = (pfz - st.r.oz) * st.r.iz;
+                    const float t1 = fminf(fminf(fx, fminf(fy, fz)), st.bound);
+                    const float t0 = fmaxf(fmaxf(nx, fmaxf(ny, nz)), 0.0f);
+                    const bool h = (t1 >= t0) && ref[k] != kNoChild;
+                    key[k] = h ? fminf(t0, 3.0e38f) : INFINITY;
                     nh += h ? 1 : 0;
                 }
                 // children in order of entry distance (misses last): five compare-exchanges
