@@ -40,7 +40,8 @@ if trace:
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     with open(os.path.join(here, "r02_trace_kernel_launches.txt"), "w") as f:
         f.write("launches of the closest-hit trace kernel in the bench's HBM-regime record, in order\n"
-                "(1 with counters, then warm-up + 3 timed in origin-cell order, then warm-up + 3 timed in queue order)\n")
+                "(2 with test counters compiled in: two-child and four-child walk; then warm-up + 3 timed in origin-cell order,\n"
+                "then warm-up + 3 timed in queue order; a last small one belongs to the CPU-baseline section)\n")
         for r in rows:
             f.write("%-60s %8.3f ms\n" % (kernel_name(r["Kernel_Name"]),
                                           (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
