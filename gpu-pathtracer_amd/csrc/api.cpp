@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -31,6 +32,22 @@ int fail(int code, const std::string &msg) {
 
 int hip_fail(hipError_t e, const char *what) {
     return fail(PT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// Device memory for a scene array.  MIPT_ALLOC_POW2 (experiment knob): sizes rounded up to a
+// power of two.
+hipError_t scene_malloc(void **dst, size_t bytes) {
+    static const int pow2 = [] {
+        const char *e = getenv("MIPT_ALLOC_POW2");
+        return e ? atoi(e) : 0;
+    }();
+    size_t want = bytes ? bytes : 16;
+    if (pow2 && want >= ((size_t)1 << 20)) {
+        size_t p = (size_t)1 << 20;
+        while (p < want) p <<= 1;
+        want = p;
+    }
+    return hipMalloc(dst, want);
 }
 
 int DeviceBuffer::reserve(size_t bytes) {
@@ -498,8 +515,8 @@ static int attach_quad(pt_context *ctx, pt_scene *sc) {
         if (top) (void)hipFree(top);
         return PT_OK;
     };
-    if (hipMalloc(&qn, node_bytes) != hipSuccess) return give_up();
-    if (hipMalloc(&qt, tri_bytes) != hipSuccess) return give_up();
+    if (scene_malloc(&qn, node_bytes) != hipSuccess) return give_up();
+    if (scene_malloc(&qt, tri_bytes) != hipSuccess) return give_up();
     if (hipMalloc(&top, cache_bytes + index_bytes + 32) != hipSuccess) return give_up();
     int32_t *index = reinterpret_cast<int32_t *>((char *)top + cache_bytes);
     uint32_t *words = reinterpret_cast<uint32_t *>((char *)top + cache_bytes + index_bytes);   // n, bad
@@ -625,7 +642,7 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
     auto sc = std::make_unique<pt_scene>();
     sc->ctx = ctx;
     auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(dst, bytes);
+        hipError_t e = scene_malloc(dst, bytes);
         if (e != hipSuccess) return e;
         sc->allocs.push_back(*dst);
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
@@ -745,7 +762,7 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
     sc->ctx = ctx;
     hipError_t e = hipSuccess;
     auto dev_alloc = [&](void **dst, size_t bytes) -> bool {
-        e = hipMalloc(dst, bytes);
+        e = scene_malloc(dst, bytes);
         if (e != hipSuccess) return false;
         sc->allocs.push_back(*dst);
         return true;

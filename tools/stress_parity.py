@@ -15,6 +15,11 @@ oracle.build()
 ctx = mipt.Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 21
 OFF = int(os.environ.get("STRESS_SEED", "0"))      # shifts the seeds of every ray set
+# STRESS_OPTIONS="extend.quad=1 extend.stack_entries=12": context options for the whole run, e.g.
+# to put every case through the four-child walk that only large scenes get by default
+for _kv in os.environ.get("STRESS_OPTIONS", "").split():
+    _k, _, _v = _kv.partition("=")
+    ctx.set_option(_k, int(_v))
 
 
 def compare(label, sc, nodes, vtx, idx, rays, int_bits):
