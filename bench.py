@@ -63,6 +63,9 @@ def parse_args():
                     help="extra pt_bvh_options_set pairs for the host BVH build (e.g. mipt.optimize_passes=2)")
     ap.add_argument("--nee", action="store_true",
                     help="next-event estimation: one shadow ray per path vertex (counted in value)")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="with one rank: still bring up torch.distributed, the communicator and the frame "
+                         "assembly as for several (rehearses the multi-GPU branches on a one-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-record", action="store_true",
                     help="skip the second roofline record (28 M-triangle scene, HBM-resident traversal)")
@@ -127,7 +130,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                          "python -m torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_distributed      # collectives and frame assembly in play
+    if multi:
+        if "MASTER_ADDR" not in os.environ:          # --force-distributed without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"),
+                              RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- host side: scene, BVH; then upload ------------------------------------------------
@@ -160,7 +167,7 @@ def main():
 
     # ---- the communicator of the frame assembly ---------------------------------------------
     comm, assembly = None, "none"
-    if world > 1:
+    if multi:
         comm, assembly = D.make_comm(ctx, rank, world, prefer_abi=args.assembly == "abi")
 
     def params(step, flags=0):
@@ -172,7 +179,7 @@ def main():
                                   flags=flags | base_flags, samples_per_pass=args.samples_per_pass, **shard)
 
     def assemble():
-        if world == 1:
+        if not multi:
             return
         if comm is not None:
             if args.sharding == "tiles":
@@ -218,7 +225,7 @@ def main():
         assemble()                # the collective's first call sets up its channels: not timed
     film.clear()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -235,14 +242,14 @@ def main():
             kernel_ms[name] += getattr(st, name + "_ms")
     assemble()                                                 # frame assembly over RCCL
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     extend_ms = kernel_ms["extend"]
 
     agg = torch.tensor([elapsed, float(rays + shadow), float(paths)], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if multi:
         mx = agg.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
@@ -348,7 +355,7 @@ def main():
     if comm is not None:
         comm.close()
     ctx.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

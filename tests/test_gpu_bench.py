@@ -49,3 +49,30 @@ def test_bench_line_small(tmp_path):
     k = d["kernel_ms_per_step"]
     assert k["extend"] > 0 and k["shade"] > 0 and k["raygen"] > 0 and k["accumulate"] > 0
     assert sum(k.values()) * 1e-3 * d["steps"] <= d["ms_per_step"] * 1e-3 * d["steps"] * 1.001
+
+
+@pytest.mark.parametrize("sharding,assembly", [("samples", "abi"), ("tiles", "abi"), ("samples", "torch"),
+                                               ("tiles", "torch")])
+def test_bench_multi_gpu_branches_with_one_rank(tmp_path, sharding, assembly):
+    """The branches that only several ranks take -- torch.distributed over RCCL, the library's
+    communicator made from a broadcast id, the strong-scaling split, frame assembly inside the
+    timed region, the reductions of the result -- run here with one rank, started by the launcher
+    exactly as a multi-GPU run is."""
+    port = 29600 + (os.getpid() + hash((sharding, assembly))) % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-distributed", "--steps", "2", "--warmup", "1",
+           "--tris", "65536", "--width", "320", "--height", "180", "--spp-per-step", "4",
+           "--sharding", sharding, "--assembly", assembly, "--no-hbm-record", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["config"]["ranks_in_communicator"] == 1
+    if assembly == "abi":
+        assert "C ABI" in d["config"]["assembly"], d["config"]["assembly"]
+    else:
+        assert d["config"]["assembly"].startswith("torch.distributed")
+    assert abs(d["config"]["samples_per_pixel_total"] - 8.0) < 1e-6      # every sample reached the film once
