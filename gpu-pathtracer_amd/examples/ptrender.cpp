@@ -129,25 +129,12 @@ int main(int argc, char **argv) {
         }
     }
 
-    // look-at camera: columns of mat3(inv_view) are right, up, back
+    // the live application's camera set-up, src/main_granite.cpp:306-308
     pt_camera cam;
-    std::memset(&cam, 0, sizeof(cam));
-    double back[3] = {eye[0] - target[0], eye[1] - target[1], eye[2] - target[2]}, right[3], up[3];
-    const double world_up[3] = {0, 1, 0};
-    normalize(back);
-    cross(world_up, back, right);
-    normalize(right);
-    cross(back, right, up);
-    const double t = std::tan(fov * 3.14159265358979323846 / 180.0 * 0.5);
-    for (int k = 0; k < 3; ++k) {
-        cam.eye[k] = (float)eye[k];
-        cam.c0[k] = (float)right[k];
-        cam.c1[k] = (float)up[k];
-        cam.c2[k] = (float)back[k];
-    }
-    cam.sx = (float)(t * (double)W / (double)H);
-    cam.sy = (float)t;
-    cam.mode = PT_CAMERA_PINHOLE;
+    const float eye_f[3] = {(float)eye[0], (float)eye[1], (float)eye[2]};
+    const float target_f[3] = {(float)target[0], (float)target[1], (float)target[2]};
+    CHECK(pt_camera_look_at(eye_f, target_f, nullptr, (float)(fov * 3.14159265358979323846 / 180.0),
+                            (float)W / (float)H, PT_CAMERA_PINHOLE, &cam));
 
     // ---- one context per GPU, and their communicator --------------------------------------------
     struct Gpu {

@@ -177,6 +177,12 @@ _PROTOS = {
                                                   C.POINTER(TraceStats)]),
     "pt_trace_any": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
     "pt_trace_any_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp]),
+    "pt_camera_from_matrices": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                          C.c_uint32, C.POINTER(Camera)]),
+    "pt_camera_from_orientation": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
+                                             C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Camera)]),
+    "pt_camera_look_at": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                    C.c_float, C.c_float, C.c_uint32, C.POINTER(Camera)]),
     "pt_raygen": (C.c_int, [_vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, _vp]),
     "pt_raygen_device": (C.c_int, [_vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, _vp]),
     "pt_depth_shade": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
@@ -790,4 +796,38 @@ def look_at_camera(eye, target, up=(0.0, 1.0, 0.0), fovy_deg=40.0, aspect=1.0,
     cam.sx = t * aspect
     cam.sy = t
     cam.mode = mode
+    return cam
+
+
+def _floats(values, n):
+    if values is None:
+        return None
+    a = np.asarray(values, dtype=np.float32).reshape(-1)
+    if a.size != n:
+        raise ValueError("expected %d floats" % n)
+    return (C.c_float * n)(*a.tolist())
+
+
+def camera_from_matrices(inv_view, inv_projection, camera_position=None, mode=PT_CAMERA_PINHOLE) -> Camera:
+    """pt_camera_from_matrices: 4x4 matrices as 16 floats, column-major (a numpy array laid out
+    as GLSL's mat4, i.e. m[column][row])."""
+    cam = Camera()
+    _check(lib.pt_camera_from_matrices(_floats(inv_view, 16), _floats(inv_projection, 16),
+                                       _floats(camera_position, 3), mode, C.byref(cam)))
+    return cam
+
+
+def camera_from_orientation(orientation_xyzw, eye_pos, fovy_radians, viewport, mode=PT_CAMERA_PINHOLE) -> Camera:
+    """pt_camera_from_orientation: the reference's Camera struct (src/camera.h:11-24)."""
+    cam = Camera()
+    _check(lib.pt_camera_from_orientation(_floats(orientation_xyzw, 4), _floats(eye_pos, 3), float(fovy_radians),
+                                          int(viewport[0]), int(viewport[1]), mode, C.byref(cam)))
+    return cam
+
+
+def camera_look_at(eye, target, up=None, fovy_radians=0.7, aspect=1.0, mode=PT_CAMERA_PINHOLE) -> Camera:
+    """pt_camera_look_at (the library's own; look_at_camera above is the binding's numpy form)."""
+    cam = Camera()
+    _check(lib.pt_camera_look_at(_floats(eye, 3), _floats(target, 3), _floats(up, 3), float(fovy_radians),
+                                 float(aspect), mode, C.byref(cam)))
     return cam

@@ -388,6 +388,28 @@ int pt_trace_any(pt_context *ctx, const pt_scene *scene, const pt_ray *rays, uin
 int pt_trace_any_device(pt_context *ctx, const pt_scene *scene, const pt_ray *rays_dev,
                         uint64_t n, int32_t *occluded_dev);
 
+/* pt_camera from what the reference's host side holds a camera in.  Arithmetic in binary64,
+ * rounded once; PT_ERR_INVALID for values that are not finite or describe no camera.
+ *
+ * pt_camera_from_matrices: the fields of Granite's `global` uniform block the shader reads --
+ * mat3(inv_view), inv_projection[0][0] and [1][1], camera_position (shaders/depth.frag:59-60,
+ * 70,74; bound by renderer_.bind_global_parameters, src/main_granite.cpp:432-433).  Both
+ * matrices are 16 floats, column-major as GLSL stores a mat4; camera_position may be NULL
+ * (the fourth column of inv_view is taken).
+ * pt_camera_from_orientation: the reference's own Camera struct, src/camera.h:11-24
+ * (orientation quaternion x,y,z,w taking camera axes to world axes, forward = orientation *
+ * (0,0,-1); eye_pos; viewport_size), with the vertical field of view the legacy application
+ * turns into image_size_norm = 2 tan(fovy/2) * (aspect, 1), src/main.cpp:1304-1309.
+ * pt_camera_look_at: FPSCamera::look_at + set_depth_range/fovy of the live application,
+ * src/main_granite.cpp:306-308; up may be NULL for (0,1,0). */
+int pt_camera_from_matrices(const float *inv_view, const float *inv_projection,
+                            const float *camera_position, uint32_t mode, pt_camera *out);
+int pt_camera_from_orientation(const float *orientation_xyzw, const float *eye_pos, float fovy_radians,
+                               uint32_t viewport_width, uint32_t viewport_height, uint32_t mode,
+                               pt_camera *out);
+int pt_camera_look_at(const float *eye, const float *target, const float *up, float fovy_radians,
+                      float aspect, uint32_t mode, pt_camera *out);
+
 /* Camera rays for every pixel of a width x height image, row-major from the top-left
  * pixel: shaders/depth.frag:47-83 with the pixel centre mapping of shaders/quad.vert:6,14
  * (PT_CAMERA_REFERENCE), or a plain pinhole (PT_CAMERA_PINHOLE). */

@@ -296,7 +296,10 @@ def test_cpp_host_program_matches_the_binding(mipt, oracle, scenes, gpu_ctx, tmp
     sc = mipt.Scene(gpu_ctx, nodes, vtx, idx, mats, mids, link_encoding=mipt.PT_LINKS_INT_BITS)
     film = mipt.Film(gpu_ctx, W, H)
     try:
-        cam = cornell_camera(mipt, W / H)
+        # the program's camera: pt_camera_look_at on its (binary32) defaults
+        cam = mipt.camera_look_at((278.0, 273.0, -800.0), (278.0, 273.0, 0.0), None,
+                                  float(np.float32(39.3 * 3.14159265358979323846 / 180.0)),
+                                  float(np.float32(W) / np.float32(H)))
         p = mipt.render_params(W, H, sample_count=5, max_depth=4, seed=9, flags=mipt.PT_RENDER_NEE)
         mipt.render(gpu_ctx, sc, cam, p, film)
         np.testing.assert_array_equal(got.view(np.uint32), film.read().view(np.uint32))
