@@ -50,12 +50,24 @@ hipError_t scene_malloc(void **dst, size_t bytes) {
     return hipMalloc(dst, want);
 }
 
-int DeviceBuffer::reserve(size_t bytes) {
+// Stack slots in global memory for the few rays that outgrow the LDS stack, for every lane of the
+// largest persistent grid (100 MB on 256 compute units); without them such rays fall back to the
+// fixed-order walk.  A ray's stack never holds more entries than the tree has levels, so a
+// context gets the slots with the first scene whose tree is deeper than the smallest LDS stack a
+// launch may be given (option "extend.stack_entries" >= 9), and keeps them.
+void ensure_stack_spill(pt_context *ctx, uint32_t tree_depth, bool two_level) {
+    if (ctx->stack_spill.ptr || (!two_level && tree_depth <= 8)) return;
+    if (ctx->stack_spill.reserve((size_t)ctx->num_cus * kMaxLanesPerCu * kSpillEntries * sizeof(int32_t),
+                                 /*exact=*/true) != PT_OK)
+        (void)hipGetLastError();
+}
+
+int DeviceBuffer::reserve(size_t bytes, bool exact) {
     if (bytes <= cap) return PT_OK;
     if (ptr) (void)hipFree(ptr);
     ptr = nullptr;
     cap = 0;
-    const size_t want = bytes + bytes / 4;
+    const size_t want = exact ? bytes : bytes + bytes / 4;
     hipError_t e = hipMalloc(&ptr, want);
     if (e != hipSuccess) {
         ptr = nullptr;
@@ -352,11 +364,8 @@ int pt_context_create(int device, pt_context **out) {
     ctx->stream = ctx->own_stream;
     HIP_CHECK(hipMalloc((void **)&ctx->counters, sizeof(DeviceTraceCounters)));
     HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(DeviceTraceCounters), ctx->stream));
-    // stack slots in global memory for the few rays that outgrow the LDS stack, for every lane
-    // of the largest persistent grid; without them such rays fall back to the fixed-order walk
-    if (ctx->stack_spill.reserve((size_t)ctx->num_cus * kMaxLanesPerCu * kSpillEntries *
-                                 sizeof(int32_t)) != PT_OK)
-        (void)hipGetLastError();
+    // (the global stack slots of rays that outgrow the LDS stack come with the first scene whose
+    // tree is deep enough to need them: ensure_stack_spill)
     // this device's address of the static scratch array of pt_trace_closest_device_static
     const int src = static_scratch_init(device);
     if (src != PT_OK) return src;
@@ -695,6 +704,7 @@ int pt_scene_create(pt_context *ctx, const pt_bbox *nodes, uint32_t n_nodes,
         if (rc == PT_OK) rc = attach_quad(ctx, sc.get());
         if (rc != PT_OK) return rc;
     }
+    ensure_stack_spill(ctx, d.wide_depth, false);
     *out = sc.release();
     return PT_OK;
     PT_CATCH
@@ -830,6 +840,7 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
         if (rc == PT_OK) rc = attach_quad(ctx, sc.get());
         if (rc != PT_OK) return rc;
     }
+    ensure_stack_spill(ctx, d.wide_depth, false);
     *out = sc.release();
     return PT_OK;
     PT_CATCH

@@ -425,6 +425,7 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
         d.n_materials = (uint32_t)mats.size();
         d.link_enc = link_encoding;
         d.wide_depth = wide_depth;
+        ensure_stack_spill(ctx, wide_depth, true);
         d.big = needs_big_addresses(tot_wnodes + top_room, tot_wtris) ? 1u : 0u;
         d.tlas = (const float4 *)upload(top_nodes, sizeof(pt_bbox) * (size_t)n_top_nodes);
         {

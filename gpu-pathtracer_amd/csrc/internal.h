@@ -18,7 +18,7 @@ int hip_fail(hipError_t e, const char *what);
 struct DeviceBuffer {
     void *ptr = nullptr;
     size_t cap = 0;
-    int reserve(size_t bytes);
+    int reserve(size_t bytes, bool exact = false);   // exact: no head-room for growth
     void release();
 };
 
@@ -53,7 +53,7 @@ struct pt_context {
     mipt::DeviceBuffer render_ws;   // wavefront state of pt_render
     mipt::DeviceBuffer sort_scratch;    // keys and order of a sorted trace call
     mipt::DeviceBuffer render_counts;   // queue sizes per pass and bounce
-    mipt::DeviceBuffer stack_spill;     // see ExtendConfig::spill (allocated with the context)
+    mipt::DeviceBuffer stack_spill;     // see ExtendConfig::spill and ensure_stack_spill
     std::vector<hipEvent_t> events;     // pool for per-kernel timing
     hipEvent_t trace_events[2] = {nullptr, nullptr};   // around the last trace call's kernel
     bool trace_timed = false;
@@ -91,6 +91,10 @@ struct pt_bvh {
     std::vector<pt_bbox> nodes;
     uint32_t link_encoding = PT_LINKS_FLOAT_VALUE;
 };
+
+namespace mipt {
+void ensure_stack_spill(pt_context *ctx, uint32_t tree_depth, bool two_level);   // api.cpp
+}
 
 struct pt_film {
     pt_context *ctx = nullptr;

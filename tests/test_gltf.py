@@ -262,7 +262,10 @@ def test_cpp_host_program_renders_the_instanced_model(mipt, gpu_ctx, tmp_path):
     two = mipt.Model(path).scene(gpu_ctx, link_encoding=mipt.PT_LINKS_INT_BITS)
     film = mipt.Film(gpu_ctx, W, H)
     try:
-        cam = mipt.look_at_camera((6.0, 4.0, 14.0), (8.0, 2.0, 0.0), fovy_deg=60.0, aspect=W / H)
+        # the program's camera: pt_camera_look_at on binary32 arguments
+        cam = mipt.camera_look_at((6.0, 4.0, 14.0), (8.0, 2.0, 0.0), None,
+                                  float(np.float32(60.0 * 3.14159265358979323846 / 180.0)),
+                                  float(np.float32(W) / np.float32(H)))
         mipt.render(gpu_ctx, two, cam, mipt.render_params(W, H, sample_count=4, max_depth=3, seed=3,
                                                           flags=mipt.PT_RENDER_NEE), film)
         want = film.read()
