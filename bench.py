@@ -9,7 +9,7 @@ Workload (the configuration the headline metric is quoted on): Sponza-class scen
 instead), 1920x1080, Lambert+GGX materials, max depth 8, Russian roulette from bounce 3.
 A step is one pass of the whole hot path -- raygen, (extend, shade) x depth, accumulate -- over
 --spp-per-step samples per pixel of the frame; the default step is 64 spp (a quarter of the
-256-spp frame the metric is quoted on; 20 steps are five such frames), rendered in passes of
+256-spp frame the metric is quoted on; the default 40 steps are ten such frames, about 5 s), rendered in passes of
 at most 32 M paths.
 Scene, BVH and film are resident in HBM before the timed region.
 
@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -69,6 +69,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-record", action="store_true",
                     help="skip the second roofline record (28 M-triangle scene, HBM-resident traversal)")
+    ap.add_argument("--no-hbm-uniform", action="store_true",
+                    help="skip the second record's companion measurement on the uniformly tessellated surface")
+    ap.add_argument("--hbm-scene", choices=["cube", "uv"], default="uv",
+                    help="tessellation of the second record's closed surface: a cube's faces pushed out to "
+                         "the sphere (uniform triangles), or latitude / longitude (two pole fans)")
     ap.add_argument("--hbm-tris", type=int, default=28_000_000)
     ap.add_argument("--hbm-rays", type=int, default=1 << 24)
     ap.add_argument("--cpu-baseline-scale", type=int, default=1,
@@ -344,6 +349,19 @@ def main():
                     out["roofline"]["counters_copied_from_profiles"] = tr["counters"]
         if not args.no_hbm_record and world == 1:
             out["roofline_hbm"] = hbm_record(args, ctx, torch, mipt, scenes)
+            if args.hbm_scene == "uv" and not args.no_hbm_uniform:
+                # The same surface without the pole fans.  A few rays through a fan make > 1000
+                # triangle tests each, a serial chain of milliseconds that half of every launch
+                # above waits for; a scanned mesh has no such fans.  Its upper tree levels are
+                # shared by all rays through the caches, so its reference-layout bytes per second
+                # exceed HBM peak: reported as a rate, not as a roofline fraction.
+                u = hbm_record(args, ctx, torch, mipt, scenes, kind="cube")
+                out["roofline_hbm"]["same_surface_uniform_tessellation"] = {
+                    k: u[k] for k in ("workload", "avg_launch_ms", "mrays_per_s_kernel", "mrays_per_s_call_incl_sort",
+                                      "nodes_per_ray", "tris_per_ray", "bytes_per_ray", "four_child_walk",
+                                      "queue_order", "hit_fraction", "tie_rays")}
+                out["roofline_hbm"]["same_surface_uniform_tessellation"]["algorithmic_gbs_over_hbm_peak"] = u["frac"]
+                out["roofline_hbm"]["same_surface_uniform_tessellation"]["queue_order"].pop("frac", None)
         if link_enc != mipt.PT_LINKS_FLOAT_VALUE:
             out["cpu_baseline_skipped"] = "the CPU restatement of the renderer reads float-valued links only"
         elif not args.no_cpu_baseline and world == 1:    # the host-core baseline belongs to the 1-GPU line
@@ -360,13 +378,15 @@ def main():
         dist.destroy_process_group()
 
 
-def hbm_record(args, ctx, torch, mipt, scenes):
+def hbm_record(args, ctx, torch, mipt, scenes, kind=None):
     """The regime the bytes-per-ray formula was written for: a scene far larger than the caches
     (28 M-triangle closed surface, 3.1 GB of traversal data, tree built on the GPU) and 2^24
     incoherent secondary rays through pt_trace_closest_device.  achieved = algorithmic bytes
     of the launch / device time of the traversal kernel alone, against HBM peak."""
     t0 = time.time()
-    vtx, idx, _, _ = scenes.displaced_sphere(args.hbm_tris, seed=7)
+    kind = kind or args.hbm_scene
+    gen = scenes.displaced_cube_sphere if kind == "cube" else scenes.displaced_sphere
+    vtx, idx, _, _ = gen(args.hbm_tris, seed=7)
     n = args.hbm_rays
     rays = scenes.surface_rays(vtx, idx, n, seed=7)
     gen_s = time.time() - t0
@@ -410,10 +430,12 @@ def hbm_record(args, ctx, torch, mipt, scenes):
            "kernel": "k_trace_ordered_persistent (four-child nodes with quantised boxes: the form "
                      "scenes beyond the caches are walked in); nodes_per_ray / tris_per_ray / bytes_per_ray "
                      "are those of the two-child walk of the same tree on the same rays",
-           "workload": "Lucy-class displaced closed surface, %d tris (%.2f GB of node + triangle records), "
-                       "%d secondary rays (origins on the surface, cosine directions, seed 7), tree built "
-                       "on the GPU with 8 optimisation passes in %.2f s" %
-                       (idx.shape[0], (64.0 * (idx.shape[0] - 1) + 48.0 * idx.shape[0]) / 1e9, n, build_s),
+           "workload": "Lucy-class displaced closed surface (%s), %d tris (%.2f GB of node + triangle "
+                       "records), %d secondary rays (origins on the surface, cosine directions, seed 7), tree "
+                       "built on the GPU with 8 optimisation passes in %.2f s" %
+                       ("latitude / longitude tessellation: two pole fans of thousands of sliver triangles" if kind == "uv"
+                        else "cube faces pushed out to the sphere: triangles of nearly uniform size",
+                        idx.shape[0], (64.0 * (idx.shape[0] - 1) + 48.0 * idx.shape[0]) / 1e9, n, build_s),
            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
            "traffic": None, "launches": 3, "avg_launch_ms": best["kernel_ms"],
            "nodes_per_ray": n_box, "tris_per_ray": n_tri, "bytes_per_ray": bpr,
@@ -427,7 +449,7 @@ def hbm_record(args, ctx, torch, mipt, scenes):
                            "frac": bpr * n / (res["queue_order"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "hit_fraction": hit_frac, "tie_rays": int(stc.tie_rays), "scene_and_rays_generated_s": round(gen_s, 1)}
     tpath = os.path.join(REPO, "profiles", "r02_traffic_hbm.json")
-    if os.path.exists(tpath) and (args.hbm_tris, n) == (28_000_000, 1 << 24):
+    if os.path.exists(tpath) and (args.hbm_tris, n, kind) == (28_000_000, 1 << 24, "uv"):
         with open(tpath) as f:
             tr = json.load(f)
         rec["traffic"] = tr["traffic_bytes_per_launch"] / 1e9

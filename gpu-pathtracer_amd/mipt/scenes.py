@@ -276,6 +276,54 @@ def displaced_sphere(n_tri: int, seed: int = 7):
     return mb.finish(mats)
 
 
+def _fbm3(rng, octaves=6):
+    """Smooth pseudo-noise on R^3 as a sum of random plane waves (seeded, resolution independent)."""
+    dirs = rng.normal(size=(octaves, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    k = dirs * (rng.uniform(1.0, 3.0, size=(octaves, 1)) * (2.0 ** np.arange(octaves))[:, None])
+    ph = rng.uniform(0, 2 * np.pi, size=octaves)
+    amp = 0.5 ** np.arange(octaves)
+
+    def f(d):
+        out = np.zeros(d.shape[:-1])
+        for o in range(octaves):
+            out += amp[o] * np.sin(2 * np.pi * (d @ k[o]) + ph[o])
+        return out
+    return f
+
+
+def displaced_cube_sphere(n_tri: int, seed: int = 7):
+    """Lucy-like stand-in without the two pole fans of `displaced_sphere`: a cube's six faces,
+    each an n x n grid, pushed out to the unit sphere and displaced along the radius by fBm of the
+    direction; ~n_tri triangles (exactly 12 n^2) of nearly uniform size, as a scanned surface has
+    them.  Faces share their edge positions, so the surface is closed."""
+    rng = np.random.default_rng(seed)
+    n = max(2, int(round((n_tri / 12.0) ** 0.5)))
+    noise = [_fbm3(rng, 6) for _ in range(2)]
+    mats = make_materials([((0.15, 0.15, 0.15), (0.75, 0.75, 0.75), (0, 0, 0), 0.2)])
+    mb = _MeshBuilder()
+    # tan-warped grid coordinates: equal angles instead of equal cube-face steps
+    g = np.tan(np.linspace(-np.pi / 4, np.pi / 4, n + 1))
+    A, B = np.meshgrid(g, g, indexing="ij")
+    one = np.ones_like(A)
+    a = (np.arange(n)[:, None] * (n + 1) + np.arange(n)[None, :]).reshape(-1)
+    b, c, e = a + (n + 1), a + (n + 1) + 1, a + 1
+    quads_out = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, e], 1)])
+    quads_in = quads_out[:, ::-1]
+    for axis in range(3):
+        for sign in (1.0, -1.0):
+            comp = [None, None, None]
+            comp[axis] = sign * one
+            comp[(axis + 1) % 3] = A
+            comp[(axis + 2) % 3] = B
+            d = np.stack(comp, -1)
+            d /= np.linalg.norm(d, axis=-1, keepdims=True)
+            # wavelengths as on `displaced_sphere`, whose noise runs once round the equator per unit
+            r = 1.0 + 0.12 * noise[0](d / 4.7) + 0.05 * noise[1](4.0 * d / 4.7)
+            mb.add((d * r[..., None]).reshape(-1, 3), quads_out if sign > 0 else quads_in, 0)
+    return mb.finish(mats)
+
+
 def clutter(n_tri: int, seed: int = 11):
     """San-Miguel-like stand-in: a courtyard shell with many small displaced blobs ("foliage")
     flattened into one mesh; ~n_tri triangles."""

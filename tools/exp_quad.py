@@ -28,7 +28,8 @@ for name in which:
                                mipt.bvh_options(**{"bvh.builder": "sah", "mipt.link_encoding": "int"}))
         sc = mipt.Scene(ctx, nodes, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
     else:
-        ctx.set_option("build.optimize_passes", 8)
+        ctx.set_option("build.optimize_passes", int(os.environ.get("PASSES", "8")))
+        ctx.set_option("build.ploc_radius", int(os.environ.get("PLOC", "0")))
         sc = mipt.Scene(ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
     n = 1 << 24 if name != "atrium" else 1 << 22
     rays = scenes.surface_rays(vtx, idx, n, seed=7)
