@@ -41,7 +41,8 @@ if trace:
     with open(os.path.join(here, "r02_trace_kernel_launches.txt"), "w") as f:
         f.write("launches of the closest-hit trace kernel in the bench's HBM-regime record, in order\n"
                 "(2 with test counters compiled in: two-child and four-child walk; then warm-up + 3 timed in origin-cell order,\n"
-                "then warm-up + 3 timed in queue order; a last small one belongs to the CPU-baseline section)\n")
+                "then warm-up + 3 timed in queue order; the same ten again on the uniformly tessellated surface;\n"
+                "a last small one belongs to the CPU-baseline section)\n")
         for r in rows:
             f.write("%-60s %8.3f ms\n" % (kernel_name(r["Kernel_Name"]),
                                           (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
@@ -56,9 +57,19 @@ for path in sorted(glob.glob(root + "/g*/**/*counter_collection.csv", recursive=
 
 
 def split_trace_kernel(name, values):
-    """The uncounted trace kernel runs 8 times per bench run: 4 in origin-cell order, then 4 in queue order."""
-    if name.startswith("k_trace_ordered_persistent<false") and len(values) == 8:
-        return {"origin-cell order": values[:4], "queue order": values[4:]}
+    """Launches of the uncounted trace kernel in a bench run, in order: on the pole-fan surface 4 in
+    origin-cell order, then 4 in queue order, then the same on the uniformly tessellated one.  With
+    four-child nodes the two orders are two kernels (without / with the LDS copy of the top), each
+    with 4 launches per surface."""
+    if name.startswith("k_trace_ordered_persistent<false"):
+        if len(values) == 8 and name.endswith("false>"):        # two-child form, one surface
+            return {"origin-cell order": values[:4], "queue order": values[4:]}
+        if len(values) == 8:                                    # four-child form, two surfaces
+            return {"": values[:4], "uniform tessellation": values[4:]}
+        if len(values) == 16:
+            return {"origin-cell order": values[:4], "queue order": values[4:8],
+                    "uniform tessellation, origin-cell order": values[8:12],
+                    "uniform tessellation, queue order": values[12:]}
     return {"": values}
 
 
@@ -116,13 +127,17 @@ if calib["fetch_size_bytes_per_launch"]:
 for fname, prefix, label, rays in (
         ("r02_traffic.json", "k_pt_extend_persistent<false", "",
          bench["config"]["rays_per_step_per_gpu"] * bench["steps"] / bench["roofline"]["launches"]),
-        ("r02_traffic_hbm.json", "k_trace_ordered_persistent<false", " [origin-cell order]", float(1 << 24))):
+        ("r02_traffic_hbm.json", "k_trace_ordered_persistent<false", " [origin-cell order]", float(1 << 24)),
+        ("r02_traffic_hbm_uniform.json", "k_trace_ordered_persistent<false", " [uniform tessellation]", float(1 << 24))):
     keys = [k for k in per_launch if k.startswith(prefix) and k.endswith(label or ">")]
-    if not keys and label:
+    quad_sorted = "k_trace_ordered_persistent<false, false, false, true>"
+    if label == " [origin-cell order]" and not keys:
         # four-child nodes: the rays in origin-cell order are traced by the variant without the
         # LDS copy of the top (template arguments <counting, cached, 64-bit, four-child>), the
-        # rays in queue order by the one with it -- two kernels of four launches each
-        keys = [k for k in per_launch if k.startswith("k_trace_ordered_persistent<false, false, false, true>")]
+        # rays in queue order by the one with it -- two kernels of four launches per surface
+        keys = [k for k in per_launch if k == quad_sorted]
+    if label == " [uniform tessellation]":
+        keys = [k for k in per_launch if k == quad_sorted + label]
     if not keys:
         print("no launches of", prefix)
         continue
