@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 profiles of the default bench run (headline workload + its HBM-regime record), on the GPU
+# Profiles of the default bench run (headline workload + its HBM-regime record), on the GPU
 # box from the repository root:   bash profiles/collect_r02.sh
 #  1. rocprofv3 --kernel-trace --stats over `python3 bench.py` (per-kernel durations, and the
 #     bench's own JSON line from the same run);
