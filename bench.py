@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--force-distributed", action="store_true",
                     help="with one rank: still bring up torch.distributed, the communicator and the frame "
                          "assembly as for several (rehearses the multi-GPU branches on a one-GPU box)")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="do not measure HBM-side traffic with rocprofv3 child passes (the committed "
+                         "profile's figure is copied instead, labelled so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-record", action="store_true",
                     help="skip the second roofline record (28 M-triangle scene, HBM-resident traversal)")
@@ -329,26 +332,48 @@ def main():
                     "triangle test, 64 B per ray) served from caches here; their ratio to HBM peak "
                     "is not a roofline fraction and may exceed 1",
         }
-        # HBM-side bytes per launch of that kernel come from hardware counters, which a
-        # benchmark cannot read on itself: they are copied from the committed rocprofv3 --pmc
-        # passes over this same command (profiles/collect_traffic.sh) when the workload matches.
+        # HBM-side bytes per launch of that kernel come from hardware counters, which a process
+        # cannot read on itself: they are measured by child passes of this script under
+        # rocprofv3 --pmc (live_traffic), or, failing that, copied from the committed passes over
+        # the same command when the workload matches, and labelled either way.
+        live = {}
+        if world == 1 and not multi and not args.no_live_counters:
+            live = live_traffic(args, want_hbm=not args.no_hbm_record)
+        rays_per_launch = rays / max(launches, 1)
+        if live.get("extend", {}).get("FETCH_SIZE") is not None and "WRITE_SIZE" in live["extend"]:
+            gb = traffic_bytes(live["extend"], rays_per_launch) / 1e9
+            out["roofline"]["traffic"] = gb
+            out["roofline"]["traffic_source"] = (
+                "GB per launch, measured by this run: two child passes of this script under rocprofv3 --pmc "
+                "(FETCH_SIZE, WRITE_SIZE; %d launches each) on the same workload, two steps"
+                % live["extend"]["launches_counted"])
+            out["roofline"]["hbm_frac_from_traffic"] = gb / (extend_ms / max(launches, 1) * 1e-3) / HBM_PEAK_GBS
+        elif live.get("error"):
+            out["roofline"]["live_counters_failed"] = live["error"]
         tpath = os.path.join(REPO, "profiles", "r02_traffic.json")
         if os.path.exists(tpath) and world == 1:
             with open(tpath) as f:
                 tr = json.load(f)
             same = tr.get("workload") == [args.tris, W, H, args.depth, spp, args.samples_per_pass,
                                           bool(args.nee), data_kind]
-            if same:
+            if same and out["roofline"]["traffic"] is None:
                 gb = tr["traffic_bytes_per_launch"] / 1e9
                 out["roofline"]["traffic"] = gb
                 out["roofline"]["traffic_source"] = ("GB per launch, copied from profiles/r02_traffic.json (rocprofv3 "
                                                      "--pmc passes over this command; FETCH_SIZE calibrated there "
                                                      "on 64-byte gathers of known size), not measured by this run")
                 out["roofline"]["hbm_frac_from_traffic"] = gb / (extend_ms / max(launches, 1) * 1e-3) / HBM_PEAK_GBS
-                if "counters" in tr:
-                    out["roofline"]["counters_copied_from_profiles"] = tr["counters"]
+            if same and "counters" in tr:
+                out["roofline"]["counters_copied_from_profiles"] = tr["counters"]
         if not args.no_hbm_record and world == 1:
             out["roofline_hbm"] = hbm_record(args, ctx, torch, mipt, scenes)
+            if live.get("trace", {}).get("FETCH_SIZE") is not None and "WRITE_SIZE" in live["trace"]:
+                h = out["roofline_hbm"]
+                h["traffic"] = traffic_bytes(live["trace"], float(args.hbm_rays)) / 1e9
+                h["traffic_source"] = ("GB per launch, measured by this run: child passes of this script under "
+                                       "rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; %d launches each)"
+                                       % live["trace"]["launches_counted"])
+                h["hbm_frac_from_traffic"] = h["traffic"] / (h["avg_launch_ms"] * 1e-3) / HBM_PEAK_GBS
             if args.hbm_scene == "uv" and not args.no_hbm_uniform:
                 # The same surface without the pole fans.  A few rays through a fan make > 1000
                 # triangle tests each, a serial chain of milliseconds that half of every launch
@@ -376,6 +401,79 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def live_traffic(args, want_hbm):
+    """HBM-side bytes per launch of the two dominant kernels, measured now: this script run again
+    as a child under `rocprofv3 --pmc`, one counter per pass as the profiler requires (FETCH_SIZE,
+    WRITE_SIZE), on the same workload with two timed steps.  Returns {"extend": {...}, "trace":
+    {...}} with the mean counter values per launch, or {} with a reason when the profiler is not
+    there or a pass fails -- the caller then falls back to the committed profile's figure."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+             "--no-live-counters", "--no-hbm-uniform", "--width", str(args.width), "--height", str(args.height),
+             "--tris", str(args.tris), "--depth", str(args.depth), "--spp-per-step", str(args.spp_per_step),
+             "--samples-per-pass", str(args.samples_per_pass), "--hbm-tris", str(args.hbm_tris),
+             "--hbm-rays", str(args.hbm_rays), "--hbm-scene", args.hbm_scene]
+    if not want_hbm:
+        child.append("--no-hbm-record")
+    if args.nee:
+        child.append("--nee")
+    if args.scene:
+        child += ["--scene", os.path.abspath(args.scene)]
+    for o in args.option:
+        child += ["--option", o]
+    for o in args.bvh_option:
+        child += ["--bvh-option", o]
+    out = {"extend": {}, "trace": {}}
+    work = tempfile.mkdtemp(prefix="mipt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "c", "--"] + child
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+            except subprocess.TimeoutExpired:
+                return {"error": "rocprofv3 --pmc %s timed out" % counter}
+            if r.returncode != 0:
+                return {"error": "rocprofv3 --pmc %s: exit %d: %s" % (counter, r.returncode, r.stderr[-300:])}
+            rows = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    rows += [x for x in csv.DictReader(f) if x.get("Counter_Name") == counter]
+            rows.sort(key=lambda x: int(x.get("Dispatch_Id", 0)))
+            ext = [float(x["Counter_Value"]) for x in rows if "k_pt_extend_persistent<false" in x["Kernel_Name"]]
+            # the uncounted trace kernel on the rays in origin-cell order: the first four launches
+            # of the variant without the LDS copy of the top (four-child nodes), or of the only
+            # variant there is (two-child nodes)
+            names = sorted({x["Kernel_Name"] for x in rows if "k_trace_ordered_persistent<false" in x["Kernel_Name"]})
+            pick = [n for n in names if "<false, false, false, true>" in n] or names
+            trc = [float(x["Counter_Value"]) for x in rows if pick and x["Kernel_Name"] == pick[0]][:4]
+            if not ext:
+                return {"error": "no launch of the extend kernel in the %s pass" % counter}
+            out["extend"][counter] = sum(ext) / len(ext)
+            out["extend"]["launches_counted"] = len(ext)
+            if trc:
+                out["trace"][counter] = sum(trc) / len(trc)
+                out["trace"]["launches_counted"] = len(trc)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return out
+
+
+def traffic_bytes(c, rays_per_launch):
+    """FETCH_SIZE and WRITE_SIZE count kilobytes.  For dependent 64-byte gathers FETCH_SIZE is the
+    byte count (checked against a gather of known size and against L2 misses x 64 B); the ray
+    queue is a wide streaming read of 32 B per ray, of which it shows half."""
+    return c["FETCH_SIZE"] * 1024.0 + 16.0 * rays_per_launch + c["WRITE_SIZE"] * 1024.0
 
 
 def hbm_record(args, ctx, torch, mipt, scenes, kind=None):

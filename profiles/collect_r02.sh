@@ -10,7 +10,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_r02
 mkdir -p $out
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py > $out/bench.json 2> $out/bench.err
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py --no-live-counters > $out/bench.json 2> $out/bench.err
 rc=$?
 echo "kernel trace rc=$rc"
 if [ $rc -ne 0 ]; then tail -5 $out/bench.err; exit $rc; fi
@@ -22,7 +22,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum TCP_GATE_EN1_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
            "TA_TA_BUSY_sum TD_TD_BUSY_sum"; do
   i=$((i+1))
-  timeout -s KILL 300 rocprofv3 --pmc $grp --output-format csv -d $out/g$i -o g$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/g$i.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc $grp --output-format csv -d $out/g$i -o g$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-counters > $out/g$i.log 2>&1
   rc=$?
   echo "group $i ($grp): rc=$rc"
   if [ $rc -ne 0 ]; then tail -3 $out/g$i.log; exit 1; fi

@@ -16,7 +16,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_line_small(tmp_path):
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1",
            "--tris", "65536", "--width", "320", "--height", "180", "--spp-per-step", "4",
-           "--hbm-tris", "200000", "--hbm-rays", "262144", "--cpu-baseline-scale", "4"]
+           "--hbm-tris", "200000", "--hbm-rays", "262144", "--cpu-baseline-scale", "4", "--no-live-counters"]
     env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-2000:]
@@ -76,3 +76,25 @@ def test_bench_multi_gpu_branches_with_one_rank(tmp_path, sharding, assembly):
     else:
         assert d["config"]["assembly"].startswith("torch.distributed")
     assert abs(d["config"]["samples_per_pixel_total"] - 8.0) < 1e-6      # every sample reached the film once
+
+
+def test_bench_measures_hbm_traffic_itself(tmp_path):
+    """roofline.traffic of a default run is not copied from a file: the benchmark runs itself again
+    under rocprofv3 --pmc (one counter per pass) and reports the bytes those passes counted."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 is not installed")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1",
+           "--tris", "65536", "--width", "320", "--height", "180", "--spp-per-step", "4",
+           "--hbm-tris", "200000", "--hbm-rays", "262144", "--no-cpu-baseline", "--no-hbm-uniform"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    r, h = d["roofline"], d["roofline_hbm"]
+    assert "live_counters_failed" not in r, r.get("live_counters_failed")
+    assert r["traffic"] is not None and r["traffic"] > 0 and "measured by this run" in r["traffic_source"]
+    assert h["traffic"] is not None and h["traffic"] > 0 and "measured by this run" in h["traffic_source"]
+    # at least the rays read and the hits written cross the memory interface
+    assert r["hbm_frac_from_traffic"] > 0 and h["hbm_frac_from_traffic"] > 0
