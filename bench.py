@@ -440,7 +440,7 @@ def live_traffic(args, want_hbm):
             d = os.path.join(work, counter)
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "c", "--"] + child
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             except subprocess.TimeoutExpired:
                 return {"error": "rocprofv3 --pmc %s timed out" % counter}
             if r.returncode != 0:
