@@ -19,7 +19,10 @@ for o in sys.argv[3:]:                      # context options, key=value
     ctx.set_option(k, int(v))
 st = torch.cuda.Stream(); torch.cuda.set_stream(st); ctx.set_stream(st.cuda_stream)
 
-vtx, idx, mats, mids = scenes.displaced_sphere(mesh_tris, seed=3)
+# MESH=cube: the uniformly tessellated surface instead of the latitude / longitude one, whose
+# pole fans give a few rays hundreds of triangle tests each
+gen = scenes.displaced_cube_sphere if os.environ.get("MESH", "uv") == "cube" else scenes.displaced_sphere
+vtx, idx, mats, mids = gen(mesh_tris, seed=3)
 ext = float(np.abs(vtx).max())
 t0 = time.perf_counter()
 nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
