@@ -4,6 +4,7 @@
 // look-at call of the live application.  Arithmetic in binary64, rounded once to binary32.
 #include <cmath>
 #include <cstring>
+#include <string>
 
 #include "../../include/mipt.h"
 
