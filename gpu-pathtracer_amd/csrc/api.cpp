@@ -147,6 +147,9 @@ ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bo
         if (ctx->extend_blocks_per_cu <= 0) c.blocks_per_cu = 5;
     }
     c.stack_entries = ctx->extend_stack_entries > 0 ? ctx->extend_stack_entries : stack;
+    // a four-child step pushes up to three entries and stops when they do not all fit: with fewer
+    // than 12 entries it would stop before a block of 8 could be moved to global memory
+    if (c.quad && c.stack_entries < 12) c.stack_entries = 12;
     c.cache_nodes = ctx->extend_cache_nodes >= 0 ? ctx->extend_cache_nodes : cache;
     return c;
 }

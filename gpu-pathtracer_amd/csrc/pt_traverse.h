@@ -674,7 +674,12 @@ __device__ __forceinline__ bool stack_service(OrderedState &st, int32_t *stack, 
                                               int base, int &spilled) {
     if (st.tie || (ANY && st.primid >= 0)) return false;
     if (st.sp > base) {
-        if ((spilled + 1) * kSpillBlock > x.entries) {
+        // Above `base` lie the run's pending entries and, on top, the node that found no room.  A
+        // block can only go out if a whole block of pending entries is there: with a small LDS
+        // stack and a four-child step (which stops up to two entries short of the end), or deep
+        // inside the stack of a two-level walk (`base` near the end), there may be fewer -- the
+        // ray is then left to the fixed-order walk, as when the global slots are used up.
+        if (st.sp - base - 2 < kSpillBlock || (spilled + 1) * kSpillBlock > x.entries) {
             st.tie = true;
             return false;
         }

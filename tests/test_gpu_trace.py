@@ -357,7 +357,7 @@ def test_stack_goes_on_in_global_memory(mipt, oracle, gpu_ctx, n):
     # pending nodes a lane can hold: LDS entries (one is kept free) + global slots.  The LDS
     # entries are set by hand here; left alone the library picks 16 or 24 by the tree's depth,
     # which the last round checks too (any number of re-resolved rays, same hits).
-    for entries in (30, 12, -1):
+    for entries in (30, 12, 9, -1):          # 9: the smallest the option takes (a four-child walk gets 12)
         gpu_ctx.set_option("extend.stack_entries", entries)
         try:
             limit = entries - 1 + 48
