@@ -7,7 +7,12 @@
 // write) is what the BVH cache offers the caller.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -40,13 +45,30 @@ struct FileCloser {
 };
 using File = std::unique_ptr<FILE, FileCloser>;
 
-// Writes header + payload to path + ".tmp" and renames it over path once everything, the close
-// included, has succeeded: an interrupted or failed save leaves the previous file as it was.
+// Writes header + payload to a staging file of its own next to path (path + ".tmp.<pid>.<n>",
+// created exclusively, so two savers of one path -- threads or processes -- never share it) and
+// renames it over path once everything, the close included, has succeeded: an interrupted or
+// failed save leaves the previous file as it was, and of several concurrent saves the last rename
+// wins with a whole file.
 int write_file_atomically(const char *who, const char *path, const void *header, size_t header_bytes,
                           const void *payload, size_t payload_bytes) {
-    const std::string tmp = std::string(path) + ".tmp";
-    FILE *f = std::fopen(tmp.c_str(), "wb");
-    if (!f) return fail(PT_ERR_IO, std::string(who) + ": cannot open " + tmp);
+    static std::atomic<unsigned> counter{0};
+    std::string tmp;
+    int fd = -1;
+    for (int attempt = 0; attempt < 64 && fd < 0; ++attempt) {
+        tmp = std::string(path) + ".tmp." + std::to_string((long long)getpid()) + "." +
+              std::to_string(counter.fetch_add(1));
+        fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_CLOEXEC, 0644);
+        if (fd < 0 && errno != EEXIST) break;
+    }
+    FILE *f = fd >= 0 ? ::fdopen(fd, "wb") : nullptr;
+    if (!f) {
+        if (fd >= 0) {
+            ::close(fd);
+            std::remove(tmp.c_str());
+        }
+        return fail(PT_ERR_IO, std::string(who) + ": cannot create " + tmp);
+    }
     bool ok = std::fwrite(header, header_bytes, 1, f) == 1 &&
               (payload_bytes == 0 || std::fwrite(payload, payload_bytes, 1, f) == 1) &&
               std::fflush(f) == 0;

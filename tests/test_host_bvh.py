@@ -246,15 +246,56 @@ def test_bvh_cache_round_trip(mipt, scenes, tmp_path):
     open(path, "wb").write(bytes(raw))
     assert mipt.lib.pt_bvh_load(path.encode(), key, mipt.C.byref(h)) == mipt.PT_ERR_IO
     assert "file size" in mipt.last_error()
-    # saves go through a temporary file: none is left behind, and a save that cannot be made
-    # leaves the target as it was
+    # saves go through a staging file of their own: none is left behind, and a save that cannot
+    # be made (the rename meets a directory) leaves no staging file either
     f, cached = mipt.build_bvh_cached(lb, path, opt)
-    assert not cached and not os.path.exists(path + ".tmp")
-    good = open(path, "rb").read()
-    os.mkdir(path + ".tmp")                       # the temporary name is taken by a directory
+    assert not cached and os.listdir(tmp_path) == ["scene.bvh"]
+    blocked = str(tmp_path / "blocked.bvh")
+    os.mkdir(blocked)
     with pytest.raises(mipt.MiptError):
-        mipt.build_bvh_cached(lb, path, mipt.bvh_options(**{"bvh.builder": "median"}))
-    assert open(path, "rb").read() == good
+        mipt.build_bvh_cached(lb, blocked, opt)
+    assert sorted(os.listdir(tmp_path)) == ["blocked.bvh", "scene.bvh"] and os.listdir(blocked) == []
+    with pytest.raises(mipt.MiptError):
+        mipt.build_bvh_cached(lb, str(tmp_path / "no_such_dir" / "x.bvh"), opt)
+
+
+def test_concurrent_saves_of_one_cache_path(mipt, scenes, tmp_path):
+    """Every rank of a multi-GPU run may miss the same cache file at once and save it: each save
+    stages into a file of its own, all succeed, and the file that remains loads."""
+    import os
+    import threading
+    vtx, idx, _, _ = scenes.random_soup(4000, seed=5)
+    lb = mipt.mesh_leaf_bounds(vtx, idx)
+    opt = mipt.bvh_options(**{"bvh.builder": "median"})
+    path = str(tmp_path / "shared.bvh")
+    want = mipt.build_bvh(lb, opt)
+    results, errors = [], []
+    start = threading.Barrier(6)
+
+    def saver():
+        try:
+            start.wait()
+            for _ in range(5):
+                h = mipt.C.c_void_p()
+                key = mipt.lib.pt_bvh_cache_key(lb.ctypes.data, lb.shape[0], mipt.C.byref(opt))
+                assert mipt.lib.pt_bvh_build(lb.ctypes.data, lb.shape[0], mipt.C.byref(opt), mipt.C.byref(h)) == 0
+                rc = mipt.lib.pt_bvh_save(h, path.encode(), key)
+                mipt.lib.pt_bvh_destroy(h)
+                results.append(rc)
+        except Exception as e:                      # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=saver) for _ in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert results == [mipt.PT_OK] * 30
+    assert os.listdir(tmp_path) == ["shared.bvh"]
+    got, cached = mipt.build_bvh_cached(lb, path, opt)
+    assert cached
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 def _sliver_scene(scenes, n=1500, seed=13):
