@@ -13,7 +13,12 @@ A step is one pass of the whole hot path -- raygen, (extend, shade) x depth, acc
 at most 32 M paths.
 Scene, BVH and film are resident in HBM before the timed region.
 
-Multi-GPU: one process per GPU, scene replicated, no collective on the data path.  Default is
+Multi-GPU: one process per GPU, scene replicated, no collective on the data path.  Started
+without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the environment), the script
+starts its N ranks itself -- a child `python -m torch.distributed.run` of this same file, before
+anything here has touched a GPU -- and relays rank 0's JSON line and the exit code; when fewer
+than N GPUs are visible it prints a one-line JSON error and exits non-zero.  The host BVH build
+runs once (rank 0 saves the tree, the others load it).  Default is
 strong scaling: the same frame (same total samples per step) is split over the ranks, by
 sample ranges or by 64x64 tiles, and assembled once over RCCL at the end of the timed region
 through the library's C ABI (pt_film_reduce / pt_film_gather_tiles), so value = rays of the
@@ -66,6 +71,9 @@ def parse_args():
     ap.add_argument("--force-distributed", action="store_true",
                     help="with one rank: still bring up torch.distributed, the communicator and the frame "
                          "assembly as for several (rehearses the multi-GPU branches on a one-GPU box)")
+    ap.add_argument("--comm-timeout", type=float, default=120.0,
+                    help="seconds a rank waits for the library's RCCL communicator to come up before every "
+                         "rank falls back to torch.distributed assembly")
     ap.add_argument("--no-live-counters", action="store_true",
                     help="do not measure HBM-side traffic with rocprofv3 child passes (the committed "
                          "profile's figure is copied instead, labelled so)")
@@ -123,26 +131,88 @@ def load_workload(args, mipt, scenes):
             "%s (%d tris)" % (os.path.basename(path), m.idx.shape[0]), "file")
 
 
+def error_line(args, message, **extra):
+    """One JSON line that says why there is no measurement (stdout, like the result line)."""
+    out = {"metric": "Mrays/s (primary+bounce), Sponza 1080p depth 8", "value": None, "unit": "Mrays/s",
+           "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "error": message}
+    out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child
+    `python -m torch.distributed.run` of this file and relay its output and exit code.  Nothing in
+    this process touches a GPU before or after (counting devices does not initialise one), so the
+    child is an ordinary subprocess, never a replacement of a process that holds the GPU."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        error_line(args, "--gpus %d but %d GPU%s visible" % (args.gpus, have, "" if have == 1 else "s"),
+                   gpus_visible=have)
+        return 2
+    with socket.socket() as s:                       # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    # the launcher sets OMP_NUM_THREADS=1 for its workers when it is unset; the ranks size their
+    # host threads from MIPT_HOST_THREADS instead (this process's CPU share, divided among them)
+    env.setdefault("MIPT_HOST_THREADS", str(max(1, host_cores() // max(1, args.gpus))))
+    env["MIPT_BENCH_LAUNCHED_BY"] = "bench.py itself (child torch.distributed.run, %d ranks)" % args.gpus
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    got_line = False
+    for line in proc.stdout:
+        got_line = got_line or line.startswith("{")
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if rc != 0 and not got_line:
+        error_line(args, "the %d-rank child run ended with exit code %d (its stderr is above)" % (args.gpus, rc))
+    return rc if rc >= 0 else 1
+
+
+def host_cores():
+    """Host threads this process may use: its CPU affinity, capped by OMP_NUM_THREADS and
+    MIPT_HOST_THREADS when set (a GPU box shows every CPU of the machine, not the share of one GPU)."""
+    n = len(os.sched_getaffinity(0))
+    for var in ("MIPT_HOST_THREADS", "OMP_NUM_THREADS"):      # the first one set decides
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) > 0:
+            return max(1, min(n, int(v)))
+    return max(1, n)
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        error_line(args, "--gpus must be at least 1")
+        return 2
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_distributed):
+        return self_launch(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            error_line(args, "--gpus %d but the launcher started %d rank%s" % (args.gpus, world, "" if world == 1 else "s"))
+        return 2
     import torch
     import torch.distributed as dist
     import mipt
     from mipt import scenes
     from mipt import distributed as D
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
-                         "python -m torch.distributed.run --nproc-per-node N")
+    if torch.cuda.device_count() <= local_rank:
+        if rank == 0:
+            error_line(args, "rank %d has no GPU: %d visible" % (local_rank, torch.cuda.device_count()),
+                       gpus_visible=torch.cuda.device_count())
+        return 2
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_distributed      # collectives and frame assembly in play
     if multi:
-        if "MASTER_ADDR" not in os.environ:          # --force-distributed without a launcher
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"),
-                              RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- host side: scene, BVH; then upload ------------------------------------------------
@@ -150,12 +220,17 @@ def main():
     t0 = time.time()
     # binned SAH as the reference configures its builder (src/main_granite.cpp:176), then two
     # rounds of insertion-based optimisation of the finished tree (untimed, like the build)
-    bvh_opts = {"bvh.builder": "sah", "mipt.optimize_passes": "2"}
+    bvh_opts = {"bvh.builder": "sah", "mipt.optimize_passes": "2", "mipt.num_threads": str(host_cores())}
     if 2 * idx.shape[0] - 1 > (1 << 24):
         bvh_opts["mipt.link_encoding"] = "int"
     bvh_opts.update(dict(o.split("=", 1) for o in args.bvh_option))
     link_enc = mipt.PT_LINKS_INT_BITS if bvh_opts.get("mipt.link_encoding") == "int" else mipt.PT_LINKS_FLOAT_VALUE
-    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**bvh_opts))
+    leaf_bounds = mipt.mesh_leaf_bounds(vtx, idx)
+    if world > 1:
+        nodes, bvh_source = D.build_bvh_once(leaf_bounds, mipt.bvh_options(**bvh_opts), rank)
+    else:
+        nodes = mipt.build_bvh(leaf_bounds, mipt.bvh_options(**bvh_opts))
+        bvh_source = "built by this process"
     build_s = time.time() - t0
     ctx = mipt.Context(local_rank)
     stream = torch.cuda.Stream()          # the library's kernels and the timing share this stream
@@ -176,7 +251,8 @@ def main():
     # ---- the communicator of the frame assembly ---------------------------------------------
     comm, assembly = None, "none"
     if multi:
-        comm, assembly = D.make_comm(ctx, rank, world, prefer_abi=args.assembly == "abi")
+        comm, assembly = D.make_comm(ctx, rank, world, prefer_abi=args.assembly == "abi",
+                                     timeout_s=args.comm_timeout)
 
     def params(step, flags=0):
         """pt_render_params of this rank for one step, or None if it has nothing to render."""
@@ -278,7 +354,7 @@ def main():
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
+            "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32", "data": data_kind,
             "msamples_per_s": total_paths / elapsed / 1e6,
@@ -292,7 +368,10 @@ def main():
                        "next_event_estimation": bool(args.nee),
                        "samples_per_pixel_total": frame_spp,
                        "bvh": ", ".join("%s=%s" % kv for kv in sorted(bvh_opts.items())),
-                       "bvh_build_s": round(build_s, 3),
+                       "bvh_build_s": round(build_s, 3), "bvh_source": bvh_source,
+                       "host_threads_per_rank": host_cores(),
+                       "launched_by": os.environ.get("MIPT_BENCH_LAUNCHED_BY", "a launcher (WORLD_SIZE was set)"
+                                                     if "WORLD_SIZE" in os.environ else "directly, one process"),
                        "sharding": "none (one GPU)" if world == 1 else
                                    ("sample ranges per rank, film summed on rank 0 at the end"
                                     if args.sharding == "samples" else
@@ -401,6 +480,12 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if D.abandoned_threads():
+        # a communicator that never came up left its thread inside RCCL: do not wait for it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    return 0
 
 
 def live_traffic(args, want_hbm):
@@ -564,8 +649,7 @@ def cpu_baseline(args, nodes, vtx, idx, mats, mids, sky, make_camera):
     import mipt
     from oracle import oracle
     oracle.build()
-    cores = len(os.sched_getaffinity(0))
-    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
+    cores = host_cores()
     s = max(1, args.cpu_baseline_scale)
     w, h = args.width // s, args.height // s
     cam = make_camera(w / h)
@@ -611,11 +695,11 @@ def traversal_counts(scene, nodes, vtx, idx, n=1 << 18):
     d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
     d_h = torch.empty_like(d_r)
     st = scene.trace_closest_device_counted(d_r.data_ptr(), n, d_h.data_ptr())
-    cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", 64))))
+    cores = host_cores()
     _, cnt = oracle.closest(nodes, vtx, idx, rays, nthreads=cores, counters=True)
     return {"rays": n, "ordered": {"box_tests_per_ray": st.box_tests / n, "tri_tests_per_ray": st.tri_tests / n},
             "skip_link_oracle": {"box_tests_per_ray": cnt.box_tests / n, "tri_tests_per_ray": cnt.tri_tests / n}}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -50,11 +50,73 @@ def step_shard_kwargs(rank: int, world: int, step: int, spp: int, scaling: str =
     return dict(sample_begin=step * per_step + rng["sample_begin"], sample_count=rng["sample_count"])
 
 
-def make_comm(ctx, rank: int, world: int, prefer_abi: bool = True, group=None):
+def build_bvh_once(leaf_bounds, options, rank: int, group=None, cache_path: str | None = None):
+    """One host BVH build for the node, not one per rank: rank 0 builds and saves the tree
+    (pt_bvh_save), the others wait and load it (pt_bvh_load checks the key of the inputs and the
+    checksum; a rank whose load fails builds for itself).  Returns (nodes, how).  Collective."""
+    import os
+    import tempfile
+    import mipt
+    if cache_path is None:
+        cache_path = os.path.join(tempfile.gettempdir(), "mipt_bvh_%s_%d.bvh"
+                                  % (os.environ.get("MASTER_PORT", "0"), os.getuid()))
+    how = "built by rank 0, loaded by the others (pt_bvh_save / pt_bvh_load)"
+    nodes = None
+    if rank == 0:
+        if os.path.exists(cache_path):
+            os.remove(cache_path)
+        nodes, _ = mipt.build_bvh_cached(leaf_bounds, cache_path, options)
+    dist.barrier(group=group)
+    if rank != 0:
+        nodes, loaded = mipt.build_bvh_cached(leaf_bounds, cache_path, options)
+        if not loaded:
+            how = "rank %d could not load rank 0's tree and built its own" % rank
+    dist.barrier(group=group)
+    if rank == 0 and os.path.exists(cache_path):
+        os.remove(cache_path)
+    return nodes, how
+
+
+_abandoned = []
+
+
+def abandoned_threads() -> int:
+    """Threads left inside a communicator set-up that did not return in time (make_comm).  A
+    process that has any should leave with os._exit once its results are out: interpreter
+    shutdown would wait on them."""
+    return sum(1 for t in _abandoned if t.is_alive())
+
+
+def _comm_with_timeout(mipt, ctx, raw: bytes, world: int, rank: int, timeout_s: float):
+    """mipt.Comm(...) on a helper thread, given up after timeout_s: ncclCommInitRank blocks until
+    every rank has joined, so one rank that cannot join would otherwise hang all of them."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["comm"] = mipt.Comm(ctx, raw, world, rank)
+        except mipt.MiptError as e:
+            box["error"] = e
+
+    t = threading.Thread(target=run, name="mipt-comm-init", daemon=True)
+    t.start()
+    t.join(timeout_s if timeout_s and timeout_s > 0 else None)
+    if t.is_alive():
+        _abandoned.append(t)
+        return None, "timed out after %.0f s" % timeout_s
+    if "comm" in box:
+        return box["comm"], ""
+    return None, str(box.get("error", "failed"))
+
+
+def make_comm(ctx, rank: int, world: int, prefer_abi: bool = True, group=None, timeout_s: float = 0.0):
     """The communicator of the frame assembly: the library's own RCCL communicator
     (pt_comm_create; its 128-byte id travels over torch.distributed), or None when the ranks
     do not all have it -- the caller then assembles with torch.distributed, which is RCCL as
-    well.  Returns (comm or None, description).  Collective: every rank calls it."""
+    well.  Returns (comm or None, description).  Collective: every rank calls it.  With
+    timeout_s > 0 a rank gives up on a communicator that has not come up by then, and with it
+    every rank does."""
     import mipt
     dev = "cuda" if torch.cuda.is_available() else "cpu"
     uid = torch.zeros(128, dtype=torch.uint8, device=dev)
@@ -71,18 +133,15 @@ def make_comm(ctx, rank: int, world: int, prefer_abi: bool = True, group=None):
     dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)
     if int(agreed.item()) == 0:
         return None, "torch.distributed (RCCL)"
-    comm = None
-    try:
-        comm = mipt.Comm(ctx, raw, world, rank)
-    except mipt.MiptError:
-        comm = None
+    comm, why = _comm_with_timeout(mipt, ctx, raw, world, rank, timeout_s)
     # a rank whose communicator did not come up takes every rank back to torch.distributed
     made = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(made, op=dist.ReduceOp.MIN, group=group)
     if int(made.item()) == 0:
         if comm is not None:
             comm.close()
-        return None, "torch.distributed (RCCL; the library's communicator did not come up on every rank)"
+        return None, ("torch.distributed (RCCL; the library's communicator did not come up on every rank%s)"
+                      % (": rank %d %s" % (rank, why) if why else ""))
     return comm, "libmipt C ABI over RCCL (pt_film_reduce / pt_film_gather_tiles)"
 
 

@@ -76,6 +76,15 @@ def _worker(rank, world, port, out_dir):
         assert len(calls) == 2
         np.save(os.path.join(out_dir, f"tiles_{rank}.npy"), ft.numpy())
 
+        # ---- one BVH build for all ranks ------------------------------------------------------
+        lb = mipt.mesh_leaf_bounds(scene[1], scene[2])
+        opt = mipt.bvh_options(**{"bvh.builder": "sah", "mipt.optimize_passes": "1"})
+        cache = os.path.join(out_dir, "once.bvh")
+        nodes_once, how = D.build_bvh_once(lb, opt, rank, cache_path=cache)
+        assert "rank 0" in how and "could not" not in how, how
+        assert not os.path.exists(cache)              # rank 0 removed it after the second barrier
+        np.save(os.path.join(out_dir, f"nodes_{rank}.npy"), nodes_once.view(np.uint32))
+
         # ---- sample ranges ------------------------------------------------------------------
         kw = D.sample_shard_kwargs(rank, world, SPP)
         film, _ = _render_shard(mipt, oracle, scene, cam, tile_size=TS, **kw)
@@ -95,7 +104,10 @@ def test_two_ranks_assemble_one_frame(tmp_path):
     mipt, oracle, scene, cam = _scene_and_camera()
     full, _ = _render_shard(mipt, oracle, scene, cam, sample_count=SPP, tile_size=TS)
     assert (full[..., 3] == SPP).all()
+    want_nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(scene[1], scene[2]),
+                                mipt.bvh_options(**{"bvh.builder": "sah", "mipt.optimize_passes": "1"}))
     for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f"nodes_{r}.npy"), want_nodes.view(np.uint32))
         tiles = np.load(tmp_path / f"tiles_{r}.npy")
         np.testing.assert_array_equal(tiles.view(np.uint32), full.view(np.uint32))
         samples = np.load(tmp_path / f"samples_{r}.npy")
@@ -147,3 +159,47 @@ def test_shard_layout_partitions_the_image():
         mipt.shard_layout(64, 64, 12, 0, 1)
     with pytest.raises(mipt.MiptError):
         mipt.shard_layout(64, 64, 16, 2, 2)
+
+
+def _run_bench(args, env=None):
+    import subprocess
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True,
+                          text=True, timeout=120, env=e)
+
+
+def test_bench_without_enough_gpus_prints_one_json_error():
+    """`python bench.py --gpus N` as the round driver starts it, on a box with fewer GPUs: one JSON
+    line with the reason and a non-zero exit code, no traceback."""
+    out = _run_bench(["--gpus", "2"])
+    assert out.returncode == 2 and "Traceback" not in out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    import json
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "GPU" in d["error"] and d["gpus_visible"] == 0
+    # started under a launcher with another rank count than --gpus says
+    out = _run_bench(["--gpus", "1"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode == 2 and "Traceback" not in out.stderr
+    assert "started 2 ranks" in json.loads(out.stdout.splitlines()[-1])["error"]
+
+
+def test_bench_starts_its_own_ranks_and_relays_their_line(monkeypatch, capsys):
+    """The self-launch path with two ranks on the CPU: bench.py, told that two GPUs are visible,
+    starts `python -m torch.distributed.run --nproc-per-node 2` of itself; the ranks find no GPU,
+    rank 0 says so in one JSON line, and the parent relays that line and a non-zero exit code."""
+    import importlib
+    import json
+    monkeypatch.syspath_prepend(REPO)
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    rc = bench.main()
+    assert rc != 0
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "has no GPU" in d["error"]

@@ -27,7 +27,7 @@ def test_bench_line_small(tmp_path):
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "roofline_hbm", "cpu_baseline"):
         assert key in d, key
     assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
     assert abs(d["config"]["samples_per_pixel_total"] - 8.0) < 1e-6      # 2 steps x 4 spp reached the film
@@ -76,6 +76,37 @@ def test_bench_multi_gpu_branches_with_one_rank(tmp_path, sharding, assembly):
     else:
         assert d["config"]["assembly"].startswith("torch.distributed")
     assert abs(d["config"]["samples_per_pixel_total"] - 8.0) < 1e-6      # every sample reached the film once
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` with no launcher around it, as the round driver starts it: the
+    script starts its ranks itself (a child torch.distributed.run) before touching a GPU and relays
+    rank 0's line.  Rehearsed with one rank (--force-distributed takes the same path); asking for
+    more GPUs than the box has gives one JSON line with the reason and a non-zero exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR",
+                                                              "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-distributed", "--steps", "2",
+           "--warmup", "1", "--tris", "65536", "--width", "320", "--height", "180", "--spp-per-step", "4",
+           "--no-hbm-record", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["launched_by"].startswith("bench.py itself")
+    assert "C ABI" in d["config"]["assembly"] and d["config"]["ranks_in_communicator"] == 1
+    assert abs(d["config"]["samples_per_pixel_total"] - 8.0) < 1e-6
+
+    import torch
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n)], capture_output=True,
+                         text=True, timeout=120, cwd=str(tmp_path), env=env)
+    assert out.returncode != 0 and "Traceback" not in out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == n and "visible" in d["error"]
 
 
 def test_bench_measures_hbm_traffic_itself(tmp_path):
