@@ -434,6 +434,15 @@ int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
     } else if (k == "build.max_levels") {
         if (v < 8 || v > 256) return fail(PT_ERR_INVALID, "build.max_levels must be in [8,256]");
         ctx->build_max_levels = (int)v;
+    } else if (k == "build.split_ratio") {
+        if (v < 0 || v > 1000000) return fail(PT_ERR_INVALID, "build.split_ratio must be in [0,1000000]");
+        ctx->build_split_ratio = (int)v;
+    } else if (k == "build.split_max") {
+        if (v < 1 || v > 256) return fail(PT_ERR_INVALID, "build.split_max must be in [1,256]");
+        ctx->build_split_max = (int)v;
+    } else if (k == "build.split_budget") {
+        if (v < 0 || v > 1000) return fail(PT_ERR_INVALID, "build.split_budget must be in [0,1000] (per cent)");
+        ctx->build_split_budget = (int)v;
     } else if (k == "trace.sort_rays") {
         if (v < -1 || v > 1) return fail(PT_ERR_INVALID, "trace.sort_rays must be -1, 0 or 1");
         ctx->trace_sort_rays = (int)v;
@@ -785,31 +794,55 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
         e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
         return e == hipSuccess;
     };
-    const uint32_t n_nodes = 2 * n_tri - 1;
     void *d_nodes, *d_vtx, *d_idx, *d_wn, *d_wt, *d_st, *d_mid, *d_mat, *d_lt = nullptr, *d_lc = nullptr;
     bool ok = upload(&d_vtx, vtx, sizeof(float) * 3 * (size_t)n_vtx) &&
               upload(&d_idx, idx, sizeof(int32_t) * 3 * (size_t)n_tri) &&
               upload(&d_mid, mids.data(), sizeof(int32_t) * mids.size()) &&
-              upload(&d_mat, mats.data(), sizeof(pt_material) * mats.size()) &&
-              dev_alloc(&d_nodes, sizeof(pt_bbox) * (size_t)n_nodes) &&
-              dev_alloc(&d_wn, sizeof(WideNode) * (size_t)(n_tri - 1)) &&
-              dev_alloc(&d_wt, sizeof(WideTriRecord) * (size_t)n_tri) &&
-              dev_alloc(&d_st, sizeof(TriRecord) * (size_t)n_tri);
+              upload(&d_mat, mats.data(), sizeof(pt_material) * mats.size());
+    // Which triangles go into several leaves is decided before anything is sized: the arrays
+    // below hold one record per leaf.
+    DeviceBuffer first_leaf;
+    uint32_t n_leaves = n_tri;
+    if (ok) {
+        const DeviceBuildResult pr = plan_triangle_splits(
+            ctx->stream, (const float *)d_vtx, (const int32_t *)d_idx, n_tri, (float)ctx->build_split_ratio,
+            ctx->build_split_max, 0.01f * (float)ctx->build_split_budget, first_leaf, n_leaves);
+        if (pr.no_memory || pr.hip_error != hipSuccess) {
+            (void)hipStreamSynchronize(ctx->stream);
+            first_leaf.release();
+            sc->release();
+            if (pr.no_memory) return PT_ERR_DEVICE;
+            return hip_fail(pr.hip_error, pr.what);
+        }
+        if (n_leaves > kMaxWideTris ||
+            (link_encoding == PT_LINKS_FLOAT_VALUE && 2ull * n_leaves - 1 > (1u << 24))) {
+            n_leaves = n_tri;                  // no room for the extra leaves: build without them
+            first_leaf.release();
+        }
+    }
+    const uint32_t n_nodes = 2 * n_leaves - 1;
+    ok = ok && dev_alloc(&d_nodes, sizeof(pt_bbox) * (size_t)n_nodes) &&
+         dev_alloc(&d_wn, sizeof(WideNode) * (size_t)(n_leaves - 1)) &&
+         dev_alloc(&d_wt, sizeof(WideTriRecord) * (size_t)n_leaves) &&
+         dev_alloc(&d_st, sizeof(TriRecord) * (size_t)n_tri);
     if (ok && !light_tri.empty())
         ok = upload(&d_lt, light_tri.data(), sizeof(int32_t) * light_tri.size()) &&
              upload(&d_lc, light_cdf.data(), sizeof(float) * light_cdf.size());
     if (!ok) {
         (void)hipStreamSynchronize(ctx->stream);
+        first_leaf.release();
         sc->release();
         return hip_fail(e, "pt_scene_build allocation / upload");
     }
     DeviceBuffer scratch;
     const DeviceBuildResult br = build_scene_on_device(
-        ctx->stream, (const float *)d_vtx, (const int32_t *)d_idx, n_tri, link_encoding, scratch,
+        ctx->stream, (const float *)d_vtx, (const int32_t *)d_idx, n_tri, n_leaves,
+        (const uint32_t *)first_leaf.ptr, link_encoding, scratch,
         (const int32_t *)d_mid, (float4 *)d_nodes, (float4 *)d_wn, (float4 *)d_wt, (float4 *)d_st,
         ctx->build_ploc_radius, ctx->build_optimize_passes, ctx->build_max_levels);
     (void)hipStreamSynchronize(ctx->stream);
     scratch.release();
+    first_leaf.release();
     if (br.no_memory || br.hip_error != hipSuccess || br.bad_input) {
         sc->release();
         if (br.bad_input)
@@ -832,11 +865,11 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
     d.light_area = light_cdf.empty() ? 0.f : light_cdf.back();
     d.n_nodes = n_nodes;
     d.n_tri = n_tri;
-    d.n_wnodes = n_tri - 1;
+    d.n_wnodes = n_leaves - 1;
     d.n_materials = (uint32_t)mats.size();
     d.link_enc = link_encoding;
     d.wide_depth = br.max_depth;
-    d.big = needs_big_addresses(n_tri - 1, n_tri) ? 1u : 0u;
+    d.big = needs_big_addresses(n_leaves - 1, n_leaves) ? 1u : 0u;
     {
         int rc = attach_top_cache(ctx, sc.get());
         if (rc == PT_OK) rc = attach_tri_leaf(ctx, sc.get());
@@ -849,8 +882,13 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
     PT_CATCH
 }
 
-int pt_scene_set_face_ids(pt_scene *scene, const int32_t *shape_ids, const int32_t *prim_ids) {
+int pt_scene_set_face_ids(pt_scene *scene, const int32_t *shape_ids, const int32_t *prim_ids,
+                          uint32_t n_triangles) {
     if (!scene) return fail(PT_ERR_INVALID, "pt_scene_set_face_ids: null scene");
+    if (shape_ids && n_triangles != scene->dev.n_tri)
+        return fail(PT_ERR_INVALID, "pt_scene_set_face_ids: " + std::to_string(n_triangles) +
+                                        " ids for a scene of " + std::to_string(scene->dev.n_tri) +
+                                        " triangles");
     if ((shape_ids == nullptr) != (prim_ids == nullptr))
         return fail(PT_ERR_INVALID, "pt_scene_set_face_ids: shape_ids and prim_ids must be given together");
     if (scene->dev.tlas)
@@ -889,6 +927,7 @@ int pt_scene_set_face_ids(pt_scene *scene, const int32_t *shape_ids, const int32
 }
 
 uint32_t pt_scene_node_count(const pt_scene *scene) { return scene ? scene->dev.n_nodes : 0; }
+uint32_t pt_scene_triangle_count(const pt_scene *scene) { return scene ? scene->dev.n_tri : 0; }
 uint32_t pt_scene_tree_depth(const pt_scene *scene) { return scene ? scene->dev.wide_depth : 0; }
 uint32_t pt_scene_link_encoding(const pt_scene *scene) { return scene ? scene->dev.link_enc : 0; }
 
@@ -925,19 +964,19 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
     const bool exact = (flags & (PT_TRACE_EXACT_ORDER | PT_TRACE_MOLLER_TRUMBORE)) != 0;
     const bool mt = (flags & PT_TRACE_MOLLER_TRUMBORE) != 0;
     const bool fixup = (flags & PT_TRACE_NO_TIE_FIXUP) == 0;
+    // pt_context_last_trace_ms answers for this call only once both of its events are recorded
+    ctx->trace_timed = false;
+    if (scene->dev.tlas && mt)
+        return fail(PT_ERR_UNSUPPORTED,
+                    "pt_trace_closest: PT_TRACE_MOLLER_TRUMBORE is not available on two-level scenes");
     HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(DeviceTraceCounters), st));
     hipEvent_t *bracket = nullptr;
-    ctx->trace_timed = false;
     if (ctx->kernel_timing && n) {
         for (hipEvent_t &e : ctx->trace_events)
             if (!e) HIP_CHECK(hipEventCreate(&e));
         bracket = ctx->trace_events;
-        ctx->trace_timed = true;
     }
     if (scene->dev.tlas) {
-        if (mt)
-            return fail(PT_ERR_UNSUPPORTED,
-                        "pt_trace_closest: PT_TRACE_MOLLER_TRUMBORE is not available on two-level scenes");
         if (bracket) HIP_CHECK(hipEventRecord(bracket[0], st));
         launch_trace_two_level(st, scene->dev, rays_dev, hits_dev, n, fixup, exact, ctx->counters,
                                count, make_extend_config(ctx, scene, false));
@@ -958,6 +997,8 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
         launch_trace_ordered(st, scene->dev, rays_dev, hits_dev, n, fixup, ctx->counters, count, cfg,
                              &ctx->sort_scratch, bracket);
     }
+    HIP_CHECK(hipGetLastError());
+    ctx->trace_timed = bracket != nullptr;
     launch_map_face_ids(st, hits_dev, n, scene->dev.face_ids);
     HIP_CHECK(hipGetLastError());
     if (stats) {
@@ -995,6 +1036,7 @@ int pt_trace_closest_device_static(pt_context *ctx, const pt_scene *scene, const
         return fail(PT_ERR_UNSUPPORTED, "pt_trace_closest_device_static: PT_TRACE_MOLLER_TRUMBORE "
                                         "is not available on two-level scenes");
     PT_TRY
+    ctx->trace_timed = false;          // this call records no events: no time to report for it
     HIP_CHECK(hipSetDevice(ctx->device));
     const int rc = launch_trace_static(ctx->stream, ctx->device, scene->dev, rays_dev, hits_dev, n,
                                        flags, make_extend_config(ctx, scene, false));

@@ -55,11 +55,114 @@ __device__ __forceinline__ float encode_index(int32_t v, uint32_t enc) {
     return enc == PT_LINKS_INT_BITS ? __int_as_float(v) : (float)v;
 }
 
+// ---- 0. triangle splitting ---------------------------------------------------------------------
+// The reference's builder has a split path (bvh.sah.use_splits -> SplitBvh,
+// src/bvh/bvh_builder.cpp:38-44): a triangle whose box is mostly empty goes into several
+// leaves with smaller boxes.  Here the decision is made per triangle before the sort: a triangle
+// whose box has `ratio` times the area its own projections need (long, thin and diagonal: the
+// slivers of a fan around a pole, a cone's tip, a cylinder's cap) is cut along the longest axis
+// of its box into equal slabs, one leaf each, whose boxes bound the triangle's part inside the
+// slab.  A fan of thousands of slivers is thousands of boxes that all cover the fan; cut this way
+// they are strings of small boxes along the slivers, and a ray through the fan meets tens of them.
+// The traversals take a triangle in several leaves as they take the host builder's.
+//
+// Half the surface area of a box, and the same for the "box" a triangle cannot do without: the
+// sum of its projections on the three coordinate planes (half the components of |e1 x e2|).
+__device__ __forceinline__ int split_pieces(const float *a, const float *b, const float *c,
+                                            float ratio, int max_pieces, float scale, uint32_t t) {
+    float ext[3], n[3];
+    for (int k = 0; k < 3; ++k)
+        ext[k] = fmaxf(fmaxf(a[k], b[k]), c[k]) - fminf(fminf(a[k], b[k]), c[k]);
+    const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    const float e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    n[0] = e1[1] * e2[2] - e1[2] * e2[1];
+    n[1] = e1[2] * e2[0] - e1[0] * e2[2];
+    n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+    const float box = (ext[0] * ext[1] + ext[0] * ext[2]) + ext[1] * ext[2];
+    const float need = 0.5f * ((fabsf(n[0]) + fabsf(n[1])) + fabsf(n[2]));
+    if (!(box > 0.f) || !(box < INFINITY) || !(need == need)) return 1;      // a point, a segment along an axis, not finite
+    // pieces = box / (ratio * need), at least 1: a piece's box then has about `ratio` times
+    // what its part of the triangle needs
+    float want = need > 0.f ? box / (ratio * need) : (float)max_pieces;
+    want = fminf(fmaxf(want, 1.f), (float)max_pieces);
+    const int k = (int)want;
+    if (scale >= 1.f) return k;
+    // over the budget: every triangle's surplus scaled down alike, the fractions rounded up or
+    // down by a fixed sequence over the triangle numbers, so that they add up and no run differs
+    const float u = (float)((t * 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
+    return 1 + (int)((float)(k - 1) * scale + u);
+}
+
+// counts[t] = leaves of triangle t (counts[n] = 0, so that the scan's last entry is the total);
+// extra: sum of (leaves - 1), for the budget.
+__global__ __launch_bounds__(kB) void k_split_count(const float *vtx, const int32_t *idx, uint32_t n,
+                                                    float ratio, int max_pieces, float scale,
+                                                    uint32_t *counts, unsigned long long *extra) {
+    const uint32_t t = blockIdx.x * kB + threadIdx.x;
+    uint32_t more = 0;
+    if (t < n) {
+        const int32_t i0 = idx[3 * (size_t)t], i1 = idx[3 * (size_t)t + 1], i2 = idx[3 * (size_t)t + 2];
+        const int k = split_pieces(vtx + 3 * (size_t)i0, vtx + 3 * (size_t)i1, vtx + 3 * (size_t)i2, ratio,
+                                   max_pieces, scale, t);
+        counts[t] = (uint32_t)k;
+        more = (uint32_t)k - 1u;
+    } else if (t == n) {
+        counts[t] = 0;
+    }
+    unsigned long long w = more;
+    for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+    if ((threadIdx.x & 63) == 0 && w) atomicAdd(extra, w);
+}
+
+// Box of the part of triangle (a, b, c) between the planes x[axis] = s0 and x[axis] = s1: the
+// vertices inside the slab and the points where the edges cross its two planes.  The crossing
+// points are computed with rounding, so the box is widened by a few units in the last place of
+// the coordinates involved and then cut back to the triangle's own box, which holds every point
+// of the triangle exactly.
+__device__ __forceinline__ void slab_box(const float *a, const float *b, const float *c, int axis,
+                                         float s0, float s1, float *mn, float *mx) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const float *v[3] = {a, b, c};
+    for (int i = 0; i < 3; ++i) {
+        const float *p = v[i], *q = v[i == 2 ? 0 : i + 1];
+        if (p[axis] >= s0 && p[axis] <= s1)
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], p[k]);
+                hi[k] = fmaxf(hi[k], p[k]);
+            }
+        for (int side = 0; side < 2; ++side) {
+            const float s = side ? s1 : s0;
+            const float dp = p[axis] - s, dq = q[axis] - s;
+            if ((dp < 0.f && dq > 0.f) || (dp > 0.f && dq < 0.f)) {
+                const float u = dp / (dp - dq);
+                for (int k = 0; k < 3; ++k) {
+                    const float x = k == axis ? s : p[k] + (q[k] - p[k]) * u;
+                    lo[k] = fminf(lo[k], x);
+                    hi[k] = fmaxf(hi[k], x);
+                }
+            }
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        const float tmin = fminf(fminf(a[k], b[k]), c[k]), tmax = fmaxf(fmaxf(a[k], b[k]), c[k]);
+        if (!(lo[k] <= hi[k])) {               // nothing of the triangle found in the slab: keep it all
+            lo[k] = tmin;
+            hi[k] = tmax;
+        }
+        const float pad = ((fabsf(tmin) + fabsf(tmax)) + (tmax - tmin)) * 9.5367431640625e-07f;   // 2^-20
+        mn[k] = fmaxf(lo[k] - pad, tmin);
+        mx[k] = fminf(hi[k] + pad, tmax);
+    }
+}
+
 // ---- 1. leaf boxes, centre bounds -----------------------------------------------------
-// boxes[t] = inflated box of triangle t (w fields 0).  bounds[0..5]: ordered-uint min x,y,z
-// and max x,y,z of the box centres; bounds[6]: set non-zero if a vertex or box is not finite.
+// boxes[r] = inflated box of leaf r (w fields 0).  Without splits leaf r is triangle r; with them
+// (first != null) the leaves of triangle t are first[t] .. first[t + 1] - 1 and leaf_tri names
+// each leaf's triangle.  bounds[0..5]: ordered-uint min x,y,z and max x,y,z of the box centres;
+// bounds[6]: set non-zero if a vertex or box is not finite.
 __global__ __launch_bounds__(kB) void k_leaf_boxes(const float *vtx, const int32_t *idx,
-                                                   uint32_t n, float4 *boxes,
+                                                   uint32_t n, const uint32_t *first,
+                                                   uint32_t *leaf_tri, float4 *boxes,
                                                    unsigned int *bounds) {
     const float kBoundsScale = 1.f + 1e-4f;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -67,20 +170,41 @@ __global__ __launch_bounds__(kB) void k_leaf_boxes(const float *vtx, const int32
     for (uint32_t t = blockIdx.x * kB + threadIdx.x; t < n; t += gridDim.x * kB) {
         const int32_t i0 = idx[3 * (size_t)t], i1 = idx[3 * (size_t)t + 1], i2 = idx[3 * (size_t)t + 2];
         const float *a = vtx + 3 * (size_t)i0, *b = vtx + 3 * (size_t)i1, *c = vtx + 3 * (size_t)i2;
-        float mn[3], mx[3];
+        const uint32_t r0 = first ? first[t] : t;
+        const uint32_t pieces = first ? first[t + 1] - r0 : 1u;
+        int axis = 0;
+        float t_lo[3], t_hi[3];
         for (int k = 0; k < 3; ++k) {
-            const float pmin = fminf(fminf(a[k], b[k]), c[k]), pmax = fmaxf(fmaxf(a[k], b[k]), c[k]);
-            const float ctr = 0.5f * (pmax + pmin);                    // bvh_builder.cpp:55-58
-            mn[k] = ctr + (pmin - ctr) * kBoundsScale;
-            mx[k] = ctr + (pmax - ctr) * kBoundsScale;
-            const float m = 0.5f * (mn[k] + mx[k]);
-            lo[k] = fminf(lo[k], m);
-            hi[k] = fmaxf(hi[k], m);
-            bad |= !(fabsf(mn[k]) < INFINITY) || !(fabsf(mx[k]) < INFINITY) ||
-                   !(fabsf((a[k] + b[k]) + c[k]) < INFINITY);   // min/max would skip a NaN vertex
+            t_lo[k] = fminf(fminf(a[k], b[k]), c[k]);
+            t_hi[k] = fmaxf(fmaxf(a[k], b[k]), c[k]);
+            bad |= !(fabsf((a[k] + b[k]) + c[k]) < INFINITY);   // min/max would skip a NaN vertex
         }
-        boxes[2 * (size_t)t + 0] = make_float4(mn[0], mn[1], mn[2], 0.f);
-        boxes[2 * (size_t)t + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
+        if (t_hi[1] - t_lo[1] > t_hi[axis] - t_lo[axis]) axis = 1;
+        if (t_hi[2] - t_lo[2] > t_hi[axis] - t_lo[axis]) axis = 2;
+        const float ext = t_hi[axis] - t_lo[axis];
+        for (uint32_t j = 0; j < pieces; ++j) {
+            float p_lo[3] = {t_lo[0], t_lo[1], t_lo[2]}, p_hi[3] = {t_hi[0], t_hi[1], t_hi[2]};
+            if (pieces > 1) {
+                // neighbouring slabs share the plane between them: the same expression on both sides
+                const float s0 = j == 0 ? t_lo[axis] : t_lo[axis] + ext * ((float)j / (float)pieces);
+                const float s1 = j + 1 == pieces ? t_hi[axis] : t_lo[axis] + ext * ((float)(j + 1) / (float)pieces);
+                slab_box(a, b, c, axis, s0, s1, p_lo, p_hi);
+            }
+            float mn[3], mx[3];
+            for (int k = 0; k < 3; ++k) {
+                const float pmin = p_lo[k], pmax = p_hi[k];
+                const float ctr = 0.5f * (pmax + pmin);                    // bvh_builder.cpp:55-58
+                mn[k] = ctr + (pmin - ctr) * kBoundsScale;
+                mx[k] = ctr + (pmax - ctr) * kBoundsScale;
+                const float m = 0.5f * (mn[k] + mx[k]);
+                lo[k] = fminf(lo[k], m);
+                hi[k] = fmaxf(hi[k], m);
+                bad |= !(fabsf(mn[k]) < INFINITY) || !(fabsf(mx[k]) < INFINITY);
+            }
+            boxes[2 * (size_t)(r0 + j) + 0] = make_float4(mn[0], mn[1], mn[2], 0.f);
+            boxes[2 * (size_t)(r0 + j) + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
+            if (leaf_tri) leaf_tri[r0 + j] = t;
+        }
     }
     __shared__ float s_lo[3][kB / 64], s_hi[3][kB / 64];
     __shared__ int s_bad;
@@ -246,6 +370,8 @@ struct EmitArgs {
     float4 *wtris;     // 3 x float4 per triangle record
     float4 *stris;     // 3 x float4 per shading record, by triangle id
     const int32_t *mat_ids;
+    const uint32_t *leaf_tri;   // leaf -> triangle, null when every triangle has one leaf
+    const uint32_t *tri_first;  // triangle -> its first leaf (with leaf_tri)
     uint32_t n;        // leaves
     uint32_t enc;
 };
@@ -281,8 +407,9 @@ __global__ __launch_bounds__(kB) void k_emit_leaf(EmitArgs a) {
     const uint32_t total = 2 * a.n - 1;
     const uint32_t p = a.leaf_parent[l];
     const uint32_t pos = 2 * l + a.lt[p >> 1] + (p & 1u);
-    const uint32_t tri = a.vals[l];
-    const float4 mn = a.boxes[2 * (size_t)tri], mx = a.boxes[2 * (size_t)tri + 1];
+    const uint32_t ref = a.vals[l];
+    const uint32_t tri = a.leaf_tri ? a.leaf_tri[ref] : ref;
+    const float4 mn = a.boxes[2 * (size_t)ref], mx = a.boxes[2 * (size_t)ref + 1];
     a.nodes[2 * (size_t)pos + 0] = make_float4(mn.x, mn.y, mn.z, encode_index((int32_t)tri, a.enc));
     a.nodes[2 * (size_t)pos + 1] =
         make_float4(mx.x, mx.y, mx.z, encode_index(pos + 1 < total ? (int32_t)(pos + 1) : -1, a.enc));
@@ -293,7 +420,8 @@ __global__ __launch_bounds__(kB) void k_emit_leaf(EmitArgs a) {
     r[0] = make_float4(v0[0], v0[1], v0[2], v1[0]);
     r[1] = make_float4(v1[1], v1[2], v2[0], v2[1]);
     r[2] = make_float4(v2[2], __int_as_float((int32_t)tri), 0.f, 0.f);
-    if (a.stris) {               // shading copy (not wanted for a mesh of a two-level scene)
+    // shading copy, by the triangle's first leaf (not wanted for a mesh of a two-level scene)
+    if (a.stris && (!a.leaf_tri || a.tri_first[tri] == ref)) {
         float4 *q = a.stris + 3 * (size_t)tri;
         q[0] = r[0];
         q[1] = r[1];
@@ -422,6 +550,7 @@ struct PlocEmitArgs {
     const float *vtx;
     const int32_t *idx;
     const int32_t *mat_ids;
+    const uint32_t *leaf_tri, *tri_first;     // as in EmitArgs
     float4 *nodes, *wnodes, *wtris, *stris;
     uint32_t n, enc;
 };
@@ -433,7 +562,8 @@ __global__ __launch_bounds__(kB) void k_ploc_emit(PlocEmitArgs a) {
     const uint32_t pos = a.t.pos[id], before = a.t.before[id];
     const float4 lo = a.t.box[2 * (size_t)id], hi = a.t.box[2 * (size_t)id + 1];
     if (id < a.n) {                                      // leaf: Morton position id
-        const uint32_t tri = a.vals[id];
+        const uint32_t ref = a.vals[id];
+        const uint32_t tri = a.leaf_tri ? a.leaf_tri[ref] : ref;
         a.nodes[2 * (size_t)pos + 0] = make_float4(lo.x, lo.y, lo.z, encode_index((int32_t)tri, a.enc));
         a.nodes[2 * (size_t)pos + 1] =
             make_float4(hi.x, hi.y, hi.z, encode_index(pos + 1 < total ? (int32_t)(pos + 1) : -1, a.enc));
@@ -445,7 +575,7 @@ __global__ __launch_bounds__(kB) void k_ploc_emit(PlocEmitArgs a) {
         r[0] = make_float4(v0[0], v0[1], v0[2], v1[0]);
         r[1] = make_float4(v1[1], v1[2], v2[0], v2[1]);
         r[2] = make_float4(v2[2], __int_as_float((int32_t)tri), 0.f, 0.f);
-        if (a.stris) {
+        if (a.stris && (!a.leaf_tri || a.tri_first[tri] == ref)) {
             float4 *q = a.stris + 3 * (size_t)tri;
             q[0] = r[0];
             q[1] = r[1];
@@ -759,7 +889,10 @@ inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kB - 1) / 
         }                                                 \
     } while (0)
 
-DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
+// n_tris triangles in n leaves; d_first (n_tris + 1 entries: first leaf of each triangle) is null
+// when n == n_tris, every triangle being one leaf.
+DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *d_idx, uint32_t n_tris,
+                             const uint32_t *d_first,
                              uint32_t n, uint32_t enc, DeviceBuffer &scratch,
                              const int32_t *d_mat_ids, float4 *d_nodes,
                              float4 *d_wnodes, float4 *d_wtris, float4 *d_stris,
@@ -783,6 +916,7 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
     const size_t o_lt = take(4 * (size_t)n);
     const size_t o_ids = take(4 * (size_t)n), o_ids2 = take(4 * (size_t)n);
     const size_t o_small = take(4 * (kMaxDepth + 16 + kUMaxDepth + 8));
+    const size_t o_leaf_tri = d_first ? take(4 * (size_t)n) : 0;
     size_t sort_bytes = 0, sort2_bytes = 0;
     BUILD_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long *)nullptr,
                                                    (unsigned long long *)nullptr, (uint32_t *)nullptr,
@@ -832,6 +966,7 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
     uint32_t *ids = (uint32_t *)(base + o_ids), *ids2 = (uint32_t *)(base + o_ids2);
     unsigned int *small = (unsigned int *)(base + o_small);       // [0..6] bounds, [16..] histogram
     unsigned int *histogram = small + 16;
+    uint32_t *leaf_tri = d_first ? (uint32_t *)(base + o_leaf_tri) : nullptr;
 
     // Optimisation passes over the tree in the common numbering, then positions and output.
     auto optimise_and_emit = [&](PlocNodes t, int32_t root) -> DeviceBuildResult {
@@ -917,6 +1052,7 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
         PlocEmitArgs ea;
         ea.t = t; ea.vals = v1; ea.vtx = d_vtx; ea.idx = d_idx; ea.mat_ids = d_mat_ids;
         ea.nodes = d_nodes; ea.wnodes = d_wnodes; ea.wtris = d_wtris; ea.stris = d_stris;
+        ea.leaf_tri = leaf_tri; ea.tri_first = d_first;
         ea.n = n; ea.enc = enc;
         hipLaunchKernelGGL(k_ploc_emit, dim3(g_all), dim3(kB), 0, st, ea);
         BUILD_CHECK(hipGetLastError());
@@ -939,8 +1075,9 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
         unsigned int init[7] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u};
         BUILD_CHECK(hipMemcpyAsync(small, init, sizeof(init), hipMemcpyHostToDevice, st));
         BUILD_CHECK(hipMemsetAsync(histogram, 0, 4 * kMaxDepth, st));
-        const unsigned int g = std::min<unsigned int>(grid_for(n), 4096);
-        hipLaunchKernelGGL(k_leaf_boxes, dim3(g), dim3(kB), 0, st, d_vtx, d_idx, n, boxes, small);
+        const unsigned int g = std::min<unsigned int>(grid_for(n_tris), 4096);
+        hipLaunchKernelGGL(k_leaf_boxes, dim3(g), dim3(kB), 0, st, d_vtx, d_idx, n_tris, d_first, leaf_tri,
+                           boxes, small);
     }
     // 2. codes, 3. sort
     hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kB), 0, st, boxes, n, small, k0, v0);
@@ -996,6 +1133,7 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
         PlocEmitArgs ea;
         ea.t = t; ea.vals = v1; ea.vtx = d_vtx; ea.idx = d_idx; ea.mat_ids = d_mat_ids;
         ea.nodes = d_nodes; ea.wnodes = d_wnodes; ea.wtris = d_wtris; ea.stris = d_stris;
+        ea.leaf_tri = leaf_tri; ea.tri_first = d_first;
         ea.n = n; ea.enc = enc;
         hipLaunchKernelGGL(k_ploc_emit, dim3(grid_for(2 * (uint64_t)n - 1)), dim3(kB), 0, st, ea);
         BUILD_CHECK(hipGetLastError());
@@ -1040,6 +1178,7 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
     a.vtx = d_vtx; a.idx = d_idx;
     a.nodes = d_nodes; a.wnodes = d_wnodes; a.wtris = d_wtris;
     a.stris = d_stris; a.mat_ids = d_mat_ids;
+    a.leaf_tri = leaf_tri; a.tri_first = d_first;
     a.n = n; a.enc = enc;
     hipLaunchKernelGGL(k_emit_inner, dim3(grid_for(n_inner)), dim3(kB), 0, st, a);
     hipLaunchKernelGGL(k_emit_leaf, dim3(grid_for(n)), dim3(kB), 0, st, a);
@@ -1051,21 +1190,70 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
 
 } // namespace
 
+DeviceBuildResult plan_triangle_splits(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
+                                       uint32_t n, float ratio, int max_pieces, float budget,
+                                       DeviceBuffer &first, uint32_t &n_leaves) {
+    DeviceBuildResult res;
+    n_leaves = n;
+    max_pieces = std::min(std::max(max_pieces, 1), 256);
+    if (!(ratio > 0.f) || max_pieces < 2 || !(budget > 0.f)) return res;
+    size_t scan_bytes = 0;
+    BUILD_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr,
+                                                 (uint32_t *)nullptr, (int)(n + 1), st));
+    DeviceBuffer tmp;
+    const size_t counts_bytes = (4 * ((size_t)n + 1) + 255) / 256 * 256;
+    if (tmp.reserve(counts_bytes + 256 + scan_bytes) != PT_OK || first.reserve(4 * ((size_t)n + 1)) != PT_OK) {
+        res.no_memory = true;
+        return res;
+    }
+    uint32_t *counts = (uint32_t *)tmp.ptr;
+    unsigned long long *extra = (unsigned long long *)((char *)tmp.ptr + counts_bytes);
+    void *scan_tmp = (char *)tmp.ptr + counts_bytes + 256;
+    // All the leaves the criterion asks for, or, if that is more than `budget` extra leaves per
+    // triangle, every triangle's surplus scaled down alike (counted in integers: deterministic;
+    // the scaled counts meet the budget to within their rounding).
+    float scale = 1.f;
+    unsigned long long h_extra = 0;
+    for (int round = 0; round < 2; ++round) {
+        BUILD_CHECK(hipMemsetAsync(extra, 0, 8, st));
+        hipLaunchKernelGGL(k_split_count, dim3(grid_for((uint64_t)n + 1)), dim3(kB), 0, st, d_vtx, d_idx, n, ratio,
+                           max_pieces, scale, counts, extra);
+        BUILD_CHECK(hipMemcpyAsync(&h_extra, extra, 8, hipMemcpyDeviceToHost, st));
+        BUILD_CHECK(hipStreamSynchronize(st));
+        const double allowed = (double)budget * (double)n;
+        if (round == 1 || (double)h_extra <= allowed) break;
+        scale = (float)(allowed / (double)h_extra);
+    }
+    if (h_extra == 0) {
+        tmp.release();
+        return res;
+    }
+    BUILD_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, counts, (uint32_t *)first.ptr,
+                                                 (int)(n + 1), st));
+    BUILD_CHECK(hipStreamSynchronize(st));
+    tmp.release();
+    n_leaves = n + (uint32_t)h_extra;
+    return res;
+}
+
 DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, const int32_t *d_idx,
-                                        uint32_t n, uint32_t enc, DeviceBuffer &scratch,
+                                        uint32_t n_tris, uint32_t n_leaves, const uint32_t *d_first,
+                                        uint32_t enc, DeviceBuffer &scratch,
                                         const int32_t *d_mat_ids, float4 *d_nodes,
                                         float4 *d_wnodes, float4 *d_wtris, float4 *d_stris,
                                         int ploc_radius, int optimize_passes, int max_levels) {
     max_levels = std::min(std::max(max_levels, 2), kUMaxDepth);
-    DeviceBuildResult res = build_once(st, d_vtx, d_idx, n, enc, scratch, d_mat_ids, d_nodes, d_wnodes,
-                                       d_wtris, d_stris, ploc_radius, optimize_passes, max_levels);
+    if (n_leaves == n_tris) d_first = nullptr;
+    DeviceBuildResult res = build_once(st, d_vtx, d_idx, n_tris, d_first, n_leaves, enc, scratch, d_mat_ids,
+                                       d_nodes, d_wnodes, d_wtris, d_stris, ploc_radius, optimize_passes,
+                                       max_levels);
     // The optimisation passes can, on contrived input, make a tree deeper than their level
     // lists reach; the radix tree cannot (its depth is bounded by the key length), so it
     // is the answer then.  The inputs are untouched and every output is written again.
     if (res.too_deep && (ploc_radius > 0 || optimize_passes > 0)) {
         (void)hipGetLastError();
-        res = build_once(st, d_vtx, d_idx, n, enc, scratch, d_mat_ids, d_nodes, d_wnodes, d_wtris,
-                         d_stris, 0, 0, max_levels);
+        res = build_once(st, d_vtx, d_idx, n_tris, d_first, n_leaves, enc, scratch, d_mat_ids, d_nodes,
+                         d_wnodes, d_wtris, d_stris, 0, 0, max_levels);
     }
     return res;
 }

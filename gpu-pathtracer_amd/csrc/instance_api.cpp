@@ -237,7 +237,7 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
                 }
             }
             const DeviceBuildResult br =
-                build_scene_on_device(ctx->stream, mv, mi, d.n_triangles, link_encoding, scratch,
+                build_scene_on_device(ctx->stream, mv, mi, d.n_triangles, d.n_triangles, nullptr, link_encoding, scratch,
                                       nullptr, mn, mw, mt, nullptr, ctx->build_ploc_radius,
                                       ctx->build_optimize_passes, ctx->build_max_levels);
             hipError_t err = br.hip_error;

@@ -47,6 +47,14 @@ struct pt_context {
     int build_ploc_radius = 0;      // option "build.ploc_radius": 0 = radix tree, else clustering
     int build_optimize_passes = 0;  // option "build.optimize_passes": insertion-based optimisation rounds
     int build_max_levels = 256;     // option "build.max_levels"
+    // Triangle splitting in the GPU builder (bvh.sah.use_splits of the reference's builder,
+    // src/bvh/bvh_builder.cpp:38-44): options "build.split_ratio" (a triangle whose box has this
+    // many times the area its projections need is cut; 0 = off), "build.split_max" (leaves per
+    // triangle at most), "build.split_budget" (extra leaves, per cent of the triangle count;
+    // the reference's bvh.sah.extra_node_budget is 0.5, bvh_builder.cpp:32)
+    int build_split_ratio = 8;
+    int build_split_max = 32;
+    int build_split_budget = 50;
     mipt::DeviceTraceCounters *counters = nullptr;
     mipt::DeviceBuffer io_rays;     // staging for the host-pointer entry points
     mipt::DeviceBuffer io_hits;

@@ -167,7 +167,8 @@ _PROTOS = {
     "pt_scene_node_count": (C.c_uint32, [_vp]),
     "pt_scene_link_encoding": (C.c_uint32, [_vp]),
     "pt_scene_tree_depth": (C.c_uint32, [_vp]),
-    "pt_scene_set_face_ids": (C.c_int, [_vp, _vp, _vp]),
+    "pt_scene_set_face_ids": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
+    "pt_scene_triangle_count": (C.c_uint32, [_vp]),
     "pt_scene_read_nodes": (C.c_int, [_vp, _vp]),
     "pt_trace_closest": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint32,
                                    C.POINTER(TraceStats)]),
@@ -530,13 +531,16 @@ class Scene:
         """pt_scene_set_face_ids: what the closest-hit queries report per triangle (None, None
         removes the table)."""
         if shape_ids is None and prim_ids is None:
-            _check(lib.pt_scene_set_face_ids(self._h, None, None))
+            _check(lib.pt_scene_set_face_ids(self._h, None, None, 0))
             return
         a = np.ascontiguousarray(shape_ids, dtype=np.int32)
         b = np.ascontiguousarray(prim_ids, dtype=np.int32)
         if a.shape != b.shape or a.ndim != 1:
             raise ValueError("shape_ids and prim_ids must be one-dimensional and of equal length")
-        _check(lib.pt_scene_set_face_ids(self._h, _ptr(a), _ptr(b)))
+        _check(lib.pt_scene_set_face_ids(self._h, _ptr(a), _ptr(b), a.shape[0]))
+
+    def triangle_count(self) -> int:
+        return int(lib.pt_scene_triangle_count(self._h))
 
     def read_nodes(self) -> np.ndarray:
         """The scene's skip-link node array."""

@@ -338,10 +338,14 @@ int pt_scene_read_mesh_nodes(pt_scene *scene, uint32_t mesh, pt_bbox *nodes);
  * for the shader to return as isect.shapeid / isect.primid (shaders/RadeonRays/bvh.glslh:342-343,
  * commented out in the checked-in shader, which returns 0 and the triangle index).  With a
  * table set, pt_trace_closest* report shapeid = shape_ids[t], primid = prim_ids[t] for a hit
- * on triangle t of the scene's index buffer; misses are unchanged.  n_triangles entries each;
- * NULL, NULL removes the table.  pt_render and its statistics are not affected.  Single-level
- * scenes only (a two-level scene reports instance and mesh triangle).  Blocking. */
-int pt_scene_set_face_ids(pt_scene *scene, const int32_t *shape_ids, const int32_t *prim_ids);
+ * on triangle t of the scene's index buffer; misses are unchanged.  n_triangles entries each,
+ * which must be the scene's triangle count (pt_scene_triangle_count; anything else is
+ * PT_ERR_INVALID); NULL, NULL removes the table.  pt_render and its statistics are not affected.
+ * Single-level scenes only (a two-level scene reports instance and mesh triangle).  Blocking. */
+int pt_scene_set_face_ids(pt_scene *scene, const int32_t *shape_ids, const int32_t *prim_ids,
+                          uint32_t n_triangles);
+/* Triangles of the scene's index buffer (of all instances, for a two-level scene). */
+uint32_t pt_scene_triangle_count(const pt_scene *scene);
 
 /* The scene's skip-link array (what pt_scene_create was given, or what pt_scene_build made):
  * for validation, caching, or a CPU traversal of the same tree.  Blocking. */

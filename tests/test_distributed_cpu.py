@@ -82,7 +82,8 @@ def _worker(rank, world, port, out_dir):
         cache = os.path.join(out_dir, "once.bvh")
         nodes_once, how = D.build_bvh_once(lb, opt, rank, cache_path=cache)
         assert "rank 0" in how and "could not" not in how, how
-        assert not os.path.exists(cache)              # rank 0 removed it after the second barrier
+        dist.barrier()
+        assert not os.path.exists(cache)              # rank 0 removed it once every rank had loaded it
         np.save(os.path.join(out_dir, f"nodes_{rank}.npy"), nodes_once.view(np.uint32))
 
         # ---- sample ranges ------------------------------------------------------------------

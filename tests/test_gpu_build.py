@@ -21,9 +21,11 @@ def algorithm(request, gpu_ctx):
     each also followed by rounds of parallel insertion-based optimisation."""
     gpu_ctx.set_option("build.ploc_radius", request.param[0])
     gpu_ctx.set_option("build.optimize_passes", request.param[1])
+    gpu_ctx.set_option("build.split_ratio", 0)           # one leaf per triangle: the tests with splits say so
     yield request.param
     gpu_ctx.set_option("build.ploc_radius", 0)
     gpu_ctx.set_option("build.optimize_passes", 0)
+    gpu_ctx.set_option("build.split_ratio", 8)
 
 
 def _check_tree(mipt, oracle, nodes, vtx, idx, enc):
@@ -208,3 +210,159 @@ def test_too_deep_a_tree_falls_back_to_the_radix_tree(mipt, oracle, gpu_ctx, alg
         assert levels[256, radius, passes] > 36, levels            # deeper than the lowered limit ...
         assert levels[36, radius, passes] == radix, levels         # ... so the radix tree it is
     assert levels[36, 8, 0] == levels[256, 8, 0]                   # plain clustering needs no level lists
+
+
+# ---- triangles in several leaves (the reference's bvh.sah.use_splits, src/bvh/bvh_builder.cpp:38-44) ----
+def _cone_fan(n=1024, seed=1):
+    """A fan of n sliver triangles around the tip of a cone standing askew (so the slivers run
+    diagonally through their boxes), closed by a base fan, plus a floor of ordinary triangles."""
+    rng = np.random.default_rng(seed)
+    phi = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    ring = np.stack([np.cos(phi), np.sin(phi), np.zeros(n)], 1)
+    tip, centre = np.array([[0.0, 0.0, 1.5]]), np.array([[0.0, 0.0, 0.0]])
+    vtx = np.concatenate([ring, tip, centre])
+    nxt = (np.arange(n) + 1) % n
+    side = np.stack([np.arange(n), nxt, np.full(n, n)], 1)
+    base = np.stack([nxt, np.arange(n), np.full(n, n + 1)], 1)
+    a = rng.normal(size=3)
+    a /= np.linalg.norm(a)
+    k = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    rot = np.eye(3) + np.sin(0.7) * k + (1 - np.cos(0.7)) * k @ k
+    vtx = vtx @ rot.T + np.array([0.3, -0.2, 0.1])
+    g = 60
+    xs, ys = np.meshgrid(np.linspace(-3, 3, g), np.linspace(-3, 3, g), indexing="ij")
+    floor = np.stack([xs.ravel(), ys.ravel(), np.full(g * g, -2.0)], 1)
+    q = (np.arange(g - 1)[:, None] * g + np.arange(g - 1)[None, :]).ravel() + len(vtx)
+    fidx = np.concatenate([np.stack([q, q + g, q + 1], 1), np.stack([q + 1, q + g, q + g + 1], 1)])
+    return (np.concatenate([vtx, floor]).astype(np.float32),
+            np.concatenate([side, base, fidx]).astype(np.int32))
+
+
+def _fan_rays(mipt, vtx, idx, n, seed):
+    """Rays towards points of the sliver triangles from all around."""
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, idx.shape[0], n)
+    w = rng.dirichlet([1, 1, 1], n).astype(np.float64)
+    p = (vtx[idx[t]].astype(np.float64) * w[:, :, None]).sum(1)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros(n, dtype=mipt.ray_dtype)
+    rays["o"][:, :3] = (p - 4.0 * d).astype(np.float32)
+    rays["o"][:, 3] = 1e30
+    rays["d"][:, :3] = d.astype(np.float32)
+    return rays
+
+
+def _check_split_tree(mipt, oracle, nodes, vtx, idx, enc=None, budget=0.5):
+    """A valid skip-link tree in which every triangle has one leaf or several; a leaf's box lies
+    inside its triangle's (inflated) box, and the boxes of a triangle's leaves cover it."""
+    enc = mipt.PT_LINKS_FLOAT_VALUE if enc is None else enc
+    T = idx.shape[0]
+    mipt.validate_bvh(nodes, T, enc)
+    raw = nodes.view(np.float32).reshape(-1, 8)
+    payload = raw[:, 3].view(np.int32) if enc == mipt.PT_LINKS_INT_BITS else raw[:, 3].astype(np.int64)
+    leaf = payload >= 0
+    L = int(leaf.sum())
+    assert nodes.shape[0] == 2 * L - 1 and T <= L <= (1 + 1.02 * budget) * T + 64
+    per_tri = np.bincount(payload[leaf], minlength=T)
+    assert per_tri.min() >= 1
+    whole = oracle.inflate(oracle.mesh_leaf_bounds(vtx, idx)).view(np.float32).reshape(-1, 8)
+    lb, lt = raw[leaf], payload[leaf]
+    slack = 4e-7 * (np.abs(whole[lt][:, [0, 1, 2, 4, 5, 6]]).max(axis=1, keepdims=True) + 1e-30)
+    assert (lb[:, 0:3] >= whole[lt, 0:3] - slack).all() and (lb[:, 4:7] <= whole[lt, 4:7] + slack).all()
+    one = per_tri[lt] == 1                                  # an uncut triangle keeps the reference's box, bit for bit
+    np.testing.assert_array_equal(lb[one][:, [0, 1, 2, 4, 5, 6]].view(np.uint32),
+                                  whole[lt[one]][:, [0, 1, 2, 4, 5, 6]].view(np.uint32))
+    # points of the cut triangles (corners, edges, inside) each lie in one of their triangle's leaves
+    rng = np.random.default_rng(5)
+    cut = np.nonzero(per_tri > 1)[0]
+    order = np.argsort(lt, kind="stable")
+    first = np.concatenate([[0], np.cumsum(per_tri)])
+    w = np.concatenate([np.eye(3), rng.dirichlet([1, 1, 1], 29), rng.dirichlet([0.3, 0.3, 0.3], 32)])
+    for t in cut[rng.permutation(len(cut))[:400]]:
+        boxes = lb[order[first[t]:first[t + 1]]].astype(np.float64)
+        pts = w @ vtx[idx[t]].astype(np.float64)
+        inside = ((pts[:, None, :] >= boxes[None, :, 0:3]) & (pts[:, None, :] <= boxes[None, :, 4:7])).all(2).any(1)
+        assert inside.all(), (t, per_tri[t])
+    return per_tri
+
+
+@pytest.mark.parametrize("scene", ["cone_fan", "pole_fans"])
+def test_split_leaves_of_fans(mipt, oracle, scenes, gpu_ctx, algorithm, scene):
+    """Long thin triangles lying askew in their boxes go into several leaves; hits stay those of the
+    oracle walking the tree read back, and of a search over all triangles; a ray through the fan
+    meets far fewer boxes."""
+    if algorithm not in ((0, 0), (0, 3), (8, 2)):
+        pytest.skip("one builder of each kind is enough here")
+    if scene == "cone_fan":
+        vtx, idx = _cone_fan()
+        rays = _fan_rays(mipt, vtx, idx[:2048], 60000, seed=3)
+    else:
+        vtx, idx, _, _ = scenes.displaced_sphere(120_000, seed=7)
+        pole = np.nonzero(np.abs(vtx[idx][:, :, 1]).max(axis=1) > 0.999 * np.abs(vtx[:, 1]).max())[0]
+        rays = np.concatenate([_fan_rays(mipt, vtx, idx[pole], 30000, seed=4),
+                               scenes.surface_rays(vtx, idx, 30000, seed=9).astype(mipt.ray_dtype)])
+    work = {}
+    try:
+        gpu_ctx.set_option("build.split_budget", 400)        # most of these small scenes is fan
+        for ratio in (0, 8):
+            gpu_ctx.set_option("build.split_ratio", ratio)
+            a = mipt.Scene(gpu_ctx, None, vtx, idx)
+            b = mipt.Scene(gpu_ctx, None, vtx, idx)
+            try:
+                nodes = a.read_nodes()
+                np.testing.assert_array_equal(nodes.view(np.uint32), b.read_nodes().view(np.uint32))
+                if ratio:
+                    per_tri = _check_split_tree(mipt, oracle, nodes, vtx, idx, budget=4.0)
+                    assert per_tri.max() > 4 and (per_tri > 1).sum() > 500      # the fans were cut
+                else:
+                    _check_tree(mipt, oracle, nodes, vtx, idx, mipt.PT_LINKS_FLOAT_VALUE)
+                got, st = a.trace_closest(rays, stats=True)
+                work[ratio] = st.box_tests / rays.shape[0]
+                want = oracle.closest(nodes, vtx, idx, rays, nthreads=8)
+                assert len(same_hits(got, want)) == 0
+                brute = oracle.brute_closest(vtx, idx, rays[:3000], nthreads=8)
+                np.testing.assert_array_equal(got["uvwt"][:3000, 3], brute["uvwt"][:, 3])
+                assert (got["primid"] >= 0).mean() > 0.5
+                rays_any = rays.copy()
+                rays_any["o"][:, 3] = 3.9
+                np.testing.assert_array_equal(a.trace_any(rays_any), oracle.any_hit(nodes, vtx, idx, rays_any, nthreads=8))
+            finally:
+                a.close()
+                b.close()
+    finally:
+        gpu_ctx.set_option("build.split_ratio", 0)
+        gpu_ctx.set_option("build.split_budget", 50)
+    # (a 346-sliver fan at the pole of the small sphere is cut into at most 6 leaves per sliver
+    # and is a small part of what these rays meet; the 1024-sliver cone is most of its scene)
+    assert work[8] < (0.6 if scene == "cone_fan" else 1.05) * work[0], work
+
+
+def test_split_budget_and_limits(mipt, oracle, gpu_ctx, algorithm):
+    """build.split_budget caps the extra leaves (every triangle's surplus scaled alike), and
+    build.split_max the leaves of one triangle."""
+    if algorithm != (0, 0):
+        pytest.skip("sets the options itself")
+    vtx, idx = _cone_fan()
+    T = idx.shape[0]
+    leaves = {}
+    try:
+        gpu_ctx.set_option("build.split_ratio", 8)
+        for budget, most in ((50, 32), (10, 32), (1000, 4), (0, 32)):
+            gpu_ctx.set_option("build.split_budget", budget)
+            gpu_ctx.set_option("build.split_max", most)
+            sc = mipt.Scene(gpu_ctx, None, vtx, idx)
+            try:
+                nodes = sc.read_nodes()
+                raw = nodes.view(np.float32).reshape(-1, 8)
+                per_tri = np.bincount(raw[:, 3].astype(np.int64)[raw[:, 3] >= 0], minlength=T)
+                leaves[budget, most] = int(per_tri.sum())
+                assert per_tri.max() <= most and per_tri.sum() - T <= 1.02 * budget * T / 100 + 64
+                mipt.validate_bvh(nodes, T, mipt.PT_LINKS_FLOAT_VALUE)
+            finally:
+                sc.close()
+    finally:
+        gpu_ctx.set_option("build.split_ratio", 0)
+        gpu_ctx.set_option("build.split_budget", 50)
+        gpu_ctx.set_option("build.split_max", 32)
+    assert leaves[0, 32] == T and leaves[10, 32] > T and leaves[50, 32] > leaves[10, 32], leaves

@@ -294,7 +294,11 @@ def test_face_ids_of_a_flattened_multi_mesh_scene(mipt, oracle, scenes, gpu_ctx)
             sc.set_face_ids(None, None)
             assert len(same_hits(sc.trace_closest(rays), want)) == 0
             with pytest.raises(mipt.MiptError, match="together"):
-                mipt._check(mipt.lib.pt_scene_set_face_ids(sc._h, mipt._ptr(shape), None))
+                mipt._check(mipt.lib.pt_scene_set_face_ids(sc._h, mipt._ptr(shape), None, len(shape)))
+            # one entry per triangle of the scene, no fewer: a short table would be read past its end
+            assert sc.triangle_count() == len(shape)
+            with pytest.raises(mipt.MiptError, match="ids for a scene of"):
+                sc.set_face_ids(shape[:-1], prim[:-1])
         finally:
             sc.close()
     # a tree built on the GPU: compare with the walk of its own array
