@@ -98,6 +98,8 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             std::vector<pt_bbox> own_nodes;      // host-built tree of a one-triangle mesh
             const pt_bbox *nodes = nullptr;      // host copy of the skip-link tree, if any
             uint32_t n_nodes = 0, n_wnodes = 0, n_wtris = 0;
+            uint32_t n_leaves = 0;               // on_gpu: leaves of the tree to build (>= triangles)
+            DeviceBuffer first_leaf;             // on_gpu: first leaf of each triangle, if any is cut
             WideBvh wide;
             uint32_t node = 0, wnode = 0, wtri = 0, vtx = 0, tri = 0;   // offsets
             pt_bbox root{};
@@ -149,9 +151,31 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
                 if (link_encoding == PT_LINKS_FLOAT_VALUE && 2ull * d.n_triangles - 1 > (1u << 24))
                     return fail(PT_ERR_INVALID, tag + "more than 2^24 nodes need PT_LINKS_INT_BITS");
                 pl.on_gpu = true;
-                pl.n_nodes = 2 * d.n_triangles - 1;
-                pl.n_wnodes = d.n_triangles - 1;
-                pl.n_wtris = d.n_triangles;
+                pl.n_leaves = d.n_triangles;
+                if (ctx->build_split_ratio > 0) {
+                    // which triangles go into several leaves decides the sizes below: counted on
+                    // a device copy of the mesh made for that alone
+                    DeviceBuffer tv, ti;
+                    const size_t vb = sizeof(float) * 3 * (size_t)d.n_vertices;
+                    const size_t ib = sizeof(int32_t) * 3 * (size_t)d.n_triangles;
+                    if (tv.reserve(vb, true) != PT_OK || ti.reserve(ib, true) != PT_OK) return PT_ERR_DEVICE;
+                    hipError_t ce = hipMemcpy(tv.ptr, d.vertices, vb, hipMemcpyHostToDevice);
+                    if (ce == hipSuccess) ce = hipMemcpy(ti.ptr, d.indices, ib, hipMemcpyHostToDevice);
+                    if (ce != hipSuccess) return hip_fail(ce, "pt_scene_create_instanced upload");
+                    const DeviceBuildResult pr = plan_triangle_splits(
+                        ctx->stream, (const float *)tv.ptr, (const int32_t *)ti.ptr, d.n_triangles,
+                        (float)ctx->build_split_ratio, ctx->build_split_max,
+                        0.01f * (float)ctx->build_split_budget, pl.first_leaf, pl.n_leaves);
+                    if (pr.no_memory) return PT_ERR_DEVICE;
+                    if (pr.hip_error != hipSuccess) return hip_fail(pr.hip_error, pr.what);
+                    if (link_encoding == PT_LINKS_FLOAT_VALUE && 2ull * pl.n_leaves - 1 > (1u << 24)) {
+                        pl.n_leaves = d.n_triangles;         // no room for the extra leaves
+                        pl.first_leaf.release();
+                    }
+                }
+                pl.n_nodes = 2 * pl.n_leaves - 1;
+                pl.n_wnodes = pl.n_leaves - 1;
+                pl.n_wtris = pl.n_leaves;
             }
             pl.node = (uint32_t)tot_nodes; pl.wnode = (uint32_t)tot_wnodes; pl.wtri = (uint32_t)tot_wtris;
             pl.vtx = (uint32_t)tot_vtx; pl.tri = (uint32_t)tot_tri;
@@ -237,7 +261,8 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
                 }
             }
             const DeviceBuildResult br =
-                build_scene_on_device(ctx->stream, mv, mi, d.n_triangles, d.n_triangles, nullptr, link_encoding, scratch,
+                build_scene_on_device(ctx->stream, mv, mi, d.n_triangles, pl.n_leaves,
+                                      (const uint32_t *)pl.first_leaf.ptr, link_encoding, scratch,
                                       nullptr, mn, mw, mt, nullptr, ctx->build_ploc_radius,
                                       ctx->build_optimize_passes, ctx->build_max_levels);
             hipError_t err = br.hip_error;

@@ -18,6 +18,10 @@ int hip_fail(hipError_t e, const char *what);
 struct DeviceBuffer {
     void *ptr = nullptr;
     size_t cap = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    ~DeviceBuffer() { release(); }
     int reserve(size_t bytes, bool exact = false);   // exact: no head-room for growth
     void release();
 };
@@ -52,8 +56,8 @@ struct pt_context {
     // many times the area its projections need is cut; 0 = off), "build.split_max" (leaves per
     // triangle at most), "build.split_budget" (extra leaves, per cent of the triangle count;
     // the reference's bvh.sah.extra_node_budget is 0.5, bvh_builder.cpp:32)
-    int build_split_ratio = 8;
-    int build_split_max = 32;
+    int build_split_ratio = 6;
+    int build_split_max = 64;
     int build_split_budget = 50;
     mipt::DeviceTraceCounters *counters = nullptr;
     mipt::DeviceBuffer io_rays;     // staging for the host-pointer entry points

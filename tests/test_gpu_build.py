@@ -25,7 +25,7 @@ def algorithm(request, gpu_ctx):
     yield request.param
     gpu_ctx.set_option("build.ploc_radius", 0)
     gpu_ctx.set_option("build.optimize_passes", 0)
-    gpu_ctx.set_option("build.split_ratio", 8)
+    gpu_ctx.set_option("build.split_ratio", 6)           # the library's default
 
 
 def _check_tree(mipt, oracle, nodes, vtx, idx, enc):
@@ -347,7 +347,7 @@ def test_split_budget_and_limits(mipt, oracle, gpu_ctx, algorithm):
     T = idx.shape[0]
     leaves = {}
     try:
-        gpu_ctx.set_option("build.split_ratio", 8)
+        gpu_ctx.set_option("build.split_ratio", 6)           # the library's default
         for budget, most in ((50, 32), (10, 32), (1000, 4), (0, 32)):
             gpu_ctx.set_option("build.split_budget", budget)
             gpu_ctx.set_option("build.split_max", most)
@@ -364,5 +364,5 @@ def test_split_budget_and_limits(mipt, oracle, gpu_ctx, algorithm):
     finally:
         gpu_ctx.set_option("build.split_ratio", 0)
         gpu_ctx.set_option("build.split_budget", 50)
-        gpu_ctx.set_option("build.split_max", 32)
+        gpu_ctx.set_option("build.split_max", 64)
     assert leaves[0, 32] == T and leaves[10, 32] > T and leaves[50, 32] > leaves[10, 32], leaves

@@ -145,7 +145,8 @@ def test_trees_built_by_the_library(mipt, oracle, gpu_ctx, encoding):
         top = scene.read_top_nodes()
         trees = [scene.read_mesh_nodes(k) for k in range(len(meshes))]
         for k, (_, v, i, _) in enumerate(meshes):
-            assert trees[k].shape[0] == 2 * i.shape[0] - 1
+            # one leaf per triangle, or several for long thin ones lying askew in their boxes
+            assert i.shape[0] <= (trees[k].shape[0] + 1) // 2 <= 1.5 * i.shape[0] + 64
             mipt.validate_bvh(trees[k], i.shape[0], enc)
         mipt.validate_bvh(top, len(sc["mesh_of"]), enc)
         rays = tl.rays_for(40000, 8, mipt.ray_dtype)

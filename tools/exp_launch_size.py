@@ -23,7 +23,8 @@ FLAGS = int(os.environ.get("FLAGS", "0"))       # 4: PT_TRACE_NO_TIE_FIXUP
 rays = scenes.surface_rays(vtx, idx, nmax, seed=7)
 d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
 d_h = torch.empty_like(d_r)
-print(json.dumps({"scene": os.environ.get("SCENE", "uv"), "tris": int(idx.shape[0]), "depth": sc.tree_depth()}), flush=True)
+print(json.dumps({"scene": os.environ.get("SCENE", "uv"), "tris": int(idx.shape[0]), "depth": sc.tree_depth(),
+                  "leaves": (int(mipt.lib.pt_scene_node_count(sc._h)) + 1) // 2}), flush=True)
 for lg in [int(x) for x in os.environ.get('LGS', '20 21 22 23 24 25').split()]:
     n = 1 << lg
     row = {"rays": n}
