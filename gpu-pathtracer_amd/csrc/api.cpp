@@ -565,7 +565,8 @@ static int attach_quad(pt_context *ctx, pt_scene *sc) {
 }
 
 // Each triangle's leaf in the skip-link array, for deciding two-candidate ties at their leaves
-// (replay_candidates).  Left out when a triangle has several leaves (a tree with spatial splits).
+// (replay_candidates): one word per triangle, or, when a triangle has several leaves (a tree
+// with spatial splits), a list per triangle.
 static int attach_tri_leaf(pt_context *ctx, pt_scene *sc) {
     const DeviceScene &d = sc->dev;
     if (d.n_tri < 2) return PT_OK;
@@ -586,12 +587,34 @@ static int attach_tri_leaf(pt_context *ctx, pt_scene *sc) {
         (void)hipFree(buf);
         return hip_fail(e, "triangle leaf table");
     }
-    if (multi) {
-        (void)hipFree(buf);
+    if (!multi) {
+        sc->allocs.push_back(buf);
+        sc->dev.tri_leaf = (const int32_t *)buf;
         return PT_OK;
     }
-    sc->allocs.push_back(buf);
-    sc->dev.tri_leaf = (const int32_t *)buf;
+    (void)hipFree(buf);
+    // Several leaves per triangle.  Without the lists such a scene still answers every query:
+    // its tied rays are then walked over the whole tree.
+    void *first = nullptr, *list = nullptr;
+    if (hipMalloc(&first, 4 * ((size_t)d.n_tri + 1)) != hipSuccess ||
+        hipMalloc(&list, 4 * (size_t)d.n_nodes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (first) (void)hipFree(first);
+        return PT_OK;
+    }
+    DeviceBuffer scratch;
+    e = build_tri_leaf_lists(ctx->stream, d.nodes, d.n_nodes, d.link_enc, d.n_tri, (uint32_t *)first,
+                             (int32_t *)list, scratch);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(first);
+        (void)hipFree(list);
+        return PT_OK;
+    }
+    sc->allocs.push_back(first);
+    sc->allocs.push_back(list);
+    sc->dev.tri_leaf_first = (const uint32_t *)first;
+    sc->dev.tri_leaf_list = (const int32_t *)list;
     return PT_OK;
 }
 

@@ -182,12 +182,18 @@ __global__ __launch_bounds__(kB) void k_leaf_boxes(const float *vtx, const int32
         if (t_hi[1] - t_lo[1] > t_hi[axis] - t_lo[axis]) axis = 1;
         if (t_hi[2] - t_lo[2] > t_hi[axis] - t_lo[axis]) axis = 2;
         const float ext = t_hi[axis] - t_lo[axis];
+        // Planes at equal steps.  (Spacing them quadratically from the corner opposite the
+        // shortest edge -- the corner the slivers of a fan share, so that the place where all
+        // their boxes meet shrinks -- was measured: the 65 K-triangle mesh of the two-level
+        // benchmark gained 7 %, the 28 M-triangle surface lost 20 %: not kept.)
+        auto plane = [&](uint32_t j) {             // the same expression for both slabs it bounds
+            return t_lo[axis] + ext * ((float)j / (float)pieces);
+        };
         for (uint32_t j = 0; j < pieces; ++j) {
             float p_lo[3] = {t_lo[0], t_lo[1], t_lo[2]}, p_hi[3] = {t_hi[0], t_hi[1], t_hi[2]};
             if (pieces > 1) {
-                // neighbouring slabs share the plane between them: the same expression on both sides
-                const float s0 = j == 0 ? t_lo[axis] : t_lo[axis] + ext * ((float)j / (float)pieces);
-                const float s1 = j + 1 == pieces ? t_hi[axis] : t_lo[axis] + ext * ((float)(j + 1) / (float)pieces);
+                const float s0 = j == 0 ? t_lo[axis] : plane(j);
+                const float s1 = j + 1 == pieces ? t_hi[axis] : plane(j + 1);
                 slab_box(a, b, c, axis, s0, s1, p_lo, p_hi);
             }
             float mn[3], mx[3];

@@ -56,7 +56,7 @@ struct pt_context {
     // many times the area its projections need is cut; 0 = off), "build.split_max" (leaves per
     // triangle at most), "build.split_budget" (extra leaves, per cent of the triangle count;
     // the reference's bvh.sah.extra_node_budget is 0.5, bvh_builder.cpp:32)
-    int build_split_ratio = 6;
+    int build_split_ratio = 4;
     int build_split_max = 64;
     int build_split_budget = 50;
     mipt::DeviceTraceCounters *counters = nullptr;

@@ -56,6 +56,11 @@ struct DeviceScene {
     // each triangle's leaf (null otherwise).  Lets a ray with two near-equal candidates be
     // decided at those two leaves instead of by a walk over the whole tree.
     const int32_t *tri_leaf;
+    // The same for single-level scenes in which triangles have several leaves (spatial splits):
+    // the leaves of triangle t are tri_leaf_list[tri_leaf_first[t] .. tri_leaf_first[t + 1]),
+    // ascending.  Null where tri_leaf is set.
+    const uint32_t *tri_leaf_first;
+    const int32_t *tri_leaf_list;
     // Single-level scenes below 4 GiB of records: the same tree with two levels folded into one,
     // as 64-byte four-child nodes whose child boxes are 8-bit offsets on a per-node grid (never
     // inside the exact boxes), and 64-byte triangle records that carry the leaf's exact box.
@@ -120,6 +125,11 @@ void launch_build_quad_top_cache(hipStream_t st, const float4 *qnodes, uint32_t 
 void launch_map_face_ids(hipStream_t st, pt_hit *hits, uint64_t n, const int2 *face_ids);
 void launch_build_tri_leaf(hipStream_t st, const float4 *nodes, uint32_t n_nodes, uint32_t link_enc,
                            uint32_t n_tri, int32_t *tri_leaf, uint32_t *multi);
+// The form for triangles with several leaves: first (n_tri + 1 words) and list (room for n_nodes
+// words, of which the first (n_nodes + 1) / 2 are the list) as in DeviceScene.  Every triangle
+// must have a leaf.  Uses `scratch`; blocks until done.  Returns a HIP error or hipSuccess.
+hipError_t build_tri_leaf_lists(hipStream_t st, const float4 *nodes, uint32_t n_nodes, uint32_t link_enc,
+                                uint32_t n_tri, uint32_t *first, int32_t *list, DeviceBuffer &scratch);
 
 // What a persistent traversal kernel is told about its own loop.
 struct PersistentParams {

@@ -183,7 +183,19 @@ __device__ __forceinline__ void traverse_skiplink(const DeviceScene &s, const fl
 // lies farther than both by more than rounding can reverse, so it neither ends up as the answer
 // nor changes what the two are compared against; and the loop reaches a leaf exactly when the
 // leaf's own box passes the slab test at the current distance (the boxes above it contain it and
-// rounding is monotonic).  Needs s.tri_leaf.
+// rounding is monotonic).  Needs s.tri_leaf, or s.tri_leaf_first / s.tri_leaf_list where
+// triangles have several leaves.
+//
+// What the candidates' leaves alone cannot show: the loop tests a leaf's box against whatever it
+// has accepted by then, which may be a third triangle farther than both candidates.  Such a
+// hit lies beyond the tie window of the answer, so it cannot keep the loop out of a box that the
+// ray enters no later than the window's end -- but it can keep it out of one entered later.
+// There are such boxes: a flat box whose entry distance was rounded up past the hit (a hit close
+// to the origin on large coordinates), and, where a triangle lies in several leaves, every leaf
+// of it that the ray passes through behind the hit point (the triangle test is the whole
+// triangle's, so the loop accepts the hit through any leaf it gets into).  A candidate leaf that
+// the ray enters at all, but beyond the window of the final distance, therefore makes the replay
+// say "undecided" (primid -1), and the caller walks the tree as the reference does.
 __device__ __forceinline__ void replay_candidates(const DeviceScene &s, const float4 ro,
                                                   const float4 rd, int32_t pa, int32_t pb,
                                                   int32_t &shapeid, int32_t &primid, float &b0,
@@ -191,17 +203,14 @@ __device__ __forceinline__ void replay_candidates(const DeviceScene &s, const fl
     const RayPre r = precompute_ray(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
     b0 = 0.f; b1 = 0.f; b2 = 0.f; tbest = ro.w;
     shapeid = -1; primid = -1;
-    int32_t na = s.tri_leaf[pa], nb = s.tri_leaf[pb];
-    if (nb < na) {
-        const int32_t tp = pa, tn = na;
-        pa = pb; na = nb;
-        pb = tp; nb = tn;
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int32_t node = k ? nb : na, tri = k ? pb : pa;
+    float latest_entry = 0.f;            // over the leaves the ray enters within its reach
+    auto leaf = [&](int32_t node, int32_t tri) {
         const float4 lo = s.nodes[2 * (int64_t)node + 0];
         const float4 hi = s.nodes[2 * (int64_t)node + 1];
+        float t0, e0;
+        if (!intersect_box(r, lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, ro.w, e0)) return;
+        latest_entry = fmaxf(latest_entry, e0);
+        if (!intersect_box(r, lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, tbest, t0)) return;
         const int32_t i0 = s.idx[3 * (int64_t)tri + 0], i1 = s.idx[3 * (int64_t)tri + 1],
                       i2 = s.idx[3 * (int64_t)tri + 2];
         const float *p0 = s.vtx + 3 * (int64_t)i0, *p1 = s.vtx + 3 * (int64_t)i1,
@@ -209,14 +218,41 @@ __device__ __forceinline__ void replay_candidates(const DeviceScene &s, const fl
         const float v0x = p0[0], v0y = p0[1], v0z = p0[2];
         const float v1x = p1[0], v1y = p1[1], v1z = p1[2];
         const float v2x = p2[0], v2y = p2[1], v2z = p2[2];
-        float t0, h0, h1, h2, ht;
-        if (intersect_box(r, lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, tbest, t0) &&
-            intersect_triangle_watertight(r, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, tbest,
+        float h0, h1, h2, ht;
+        if (intersect_triangle_watertight(r, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, tbest,
                                           h0, h1, h2, ht)) {
             b0 = h0; b1 = h1; b2 = h2; tbest = ht;
             primid = tri;
             shapeid = 0;
         }
+    };
+    if (s.tri_leaf) {
+        int32_t na = s.tri_leaf[pa], nb = s.tri_leaf[pb];
+        if (nb < na) {
+            const int32_t tp = pa, tn = na;
+            pa = pb; na = nb;
+            pb = tp; nb = tn;
+        }
+        leaf(na, pa);
+        leaf(nb, pb);
+    } else {
+        uint32_t ia = s.tri_leaf_first[pa], ib = s.tri_leaf_first[pb];
+        const uint32_t ea = s.tri_leaf_first[pa + 1], eb = s.tri_leaf_first[pb + 1];
+        while (ia < ea || ib < eb) {                 // the two ascending lists, merged
+            const int32_t na = ia < ea ? s.tri_leaf_list[ia] : INT_MAX;
+            const int32_t nb = ib < eb ? s.tri_leaf_list[ib] : INT_MAX;
+            if (na < nb) {
+                leaf(na, pa);
+                ++ia;
+            } else {
+                leaf(nb, pb);
+                ++ib;
+            }
+        }
+    }
+    if (!(latest_entry <= tbest + tbest * PT_TIE_WINDOW)) {
+        primid = -1;
+        shapeid = -1;
     }
 }
 
@@ -1117,11 +1153,15 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                     // accept -- unless the search was cut short by a value that is not finite.
                     float lim = INFINITY, lim_bound = INFINITY;
                     uint32_t mark = my_ray;
-                    if (s.tri_leaf && !st.tie && st.primid >= 0 && st.other >= 0) {
+                    if ((s.tri_leaf || s.tri_leaf_first) && !st.tie && st.primid >= 0 && st.other >= 0) {
                         mark |= kReplay;
                         lim = __int_as_float(st.primid);
                         lim_bound = __int_as_float(st.other);
-                    } else if (!st.wild && st.primid >= 0) {
+                    } else if (s.tri_leaf && !st.wild && st.primid >= 0) {
+                        // (Only where every triangle has one leaf: a triangle in several leaves
+                        // can be accepted through a leaf that the ray enters behind the hit, if
+                        // the loop gets there while it still holds something farther -- a walk
+                        // that starts culling at the hit would pass such a leaf by.)
                         lim_bound = st.tbest + st.tbest * PT_TIE_WINDOW;
                         // The walk must enter every box on the way to that hit.  A box's computed
                         // entry distance can lie past the computed hit distance by rounding (a flat

@@ -391,6 +391,27 @@ __global__ void k_build_tri_leaf(const float4 *nodes, uint32_t n_nodes, uint32_t
     if (payload < 0 || (uint32_t)payload >= n_tri) return;
     if (atomicCAS(&tri_leaf[payload], -1, (int32_t)i) != -1) atomicOr(multi, 1u);
 }
+// keys[i] = triangle of leaf node i, or 0xFFFFFFFF for an inner node; vals[i] = i
+__global__ void k_leaf_keys(const float4 *nodes, uint32_t n_nodes, uint32_t link_enc, uint32_t n_tri,
+                            uint32_t *keys, uint32_t *vals) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int32_t payload = decode_link(nodes[2 * (size_t)i].w, link_enc);
+    keys[i] = (payload >= 0 && (uint32_t)payload < n_tri) ? (uint32_t)payload : 0xFFFFFFFFu;
+    vals[i] = i;
+}
+// sorted by triangle (stable, so each triangle's leaves ascend): where each triangle's run starts
+__global__ void k_leaf_runs(const uint32_t *keys, uint32_t n_nodes, uint32_t n_tri, uint32_t *first) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n_nodes) return;
+    const uint32_t k = keys[j];
+    if (k == 0xFFFFFFFFu) {
+        if (j == 0 || keys[j - 1] != 0xFFFFFFFFu) first[n_tri] = j;      // end of the last run
+        return;
+    }
+    if (j == 0 || keys[j - 1] != k) first[k] = j;
+    if (j + 1 == n_nodes) first[n_tri] = n_nodes;                          // no inner node: one leaf
+}
 __global__ void k_map_face_ids(pt_hit *hits, uint64_t n, const int2 *face_ids) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -410,6 +431,27 @@ void launch_build_tri_leaf(hipStream_t st, const float4 *nodes, uint32_t n_nodes
                            uint32_t n_tri, int32_t *tri_leaf, uint32_t *multi) {
     hipLaunchKernelGGL(k_build_tri_leaf, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, nodes,
                        n_nodes, link_enc, n_tri, tri_leaf, multi);
+}
+
+hipError_t build_tri_leaf_lists(hipStream_t st, const float4 *nodes, uint32_t n_nodes, uint32_t link_enc,
+                                uint32_t n_tri, uint32_t *first, int32_t *list, DeviceBuffer &scratch) {
+    size_t sort_bytes = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                                      (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_nodes, 0, 32, st);
+    if (e != hipSuccess) return e;
+    const size_t arr = (4 * (size_t)n_nodes + 255) / 256 * 256;
+    if (scratch.reserve(3 * arr + sort_bytes) != PT_OK) return hipErrorOutOfMemory;
+    char *base = (char *)scratch.ptr;
+    uint32_t *k0 = (uint32_t *)base, *k1 = (uint32_t *)(base + arr), *v0 = (uint32_t *)(base + 2 * arr);
+    const unsigned int grid = (n_nodes + 255u) / 256u;
+    hipLaunchKernelGGL(k_leaf_keys, dim3(grid), dim3(256), 0, st, nodes, n_nodes, link_enc, n_tri, k0, v0);
+    e = hipcub::DeviceRadixSort::SortPairs(base + 3 * arr, sort_bytes, k0, k1, v0, (uint32_t *)list, (int)n_nodes,
+                                           0, 32, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_leaf_runs, dim3(grid), dim3(256), 0, st, k1, n_nodes, n_tri, first);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    return e;
 }
 
 unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &cfg,

@@ -91,9 +91,9 @@ def test_lucy_class_28m_secondary_rays_gpu_built_tree(mipt, oracle, scenes, gpu_
         assert 0.4 < (got["primid"] >= 0).mean() < 0.95
         assert got["primid"].max() > 2 ** 24
         nodes = sc.read_nodes()                           # the tree the GPU built, 58 M nodes
-        # the slivers around the two poles are in several leaves each: a few per cent more leaves
+        # the slivers around the two poles are in several leaves each: an eighth more leaves
         leaves = (nodes.shape[0] + 1) // 2
-        assert idx.shape[0] < leaves < 1.1 * idx.shape[0]
+        assert idx.shape[0] < leaves < 1.25 * idx.shape[0]
         pick = sub[:20_000]
         want = oracle.closest(nodes, vtx, idx, rays[pick], nthreads=16, int_bits=True)
         assert len(same_hits(got[pick], want)) == 0
@@ -128,7 +128,7 @@ def test_scene_beyond_four_gib_of_records(mipt, oracle, scenes, gpu_ctx):
         pick = np.random.default_rng(5).choice(len(rays), 50_000, replace=False)
         assert len(same_hits(sc.trace_closest(rays[pick], mipt.PT_TRACE_EXACT_ORDER), got[pick])) == 0
         nodes = sc.read_nodes()
-        assert idx.shape[0] <= (nodes.shape[0] + 1) // 2 < 1.1 * idx.shape[0]
+        assert idx.shape[0] <= (nodes.shape[0] + 1) // 2 < 1.25 * idx.shape[0]
         want = oracle.closest(nodes, vtx, idx, rays[pick[:20_000]], nthreads=16, int_bits=True)
         assert len(same_hits(got[pick[:20_000]], want)) == 0
         occ = sc.trace_any(rays[pick])

@@ -25,7 +25,13 @@ gen = scenes.displaced_cube_sphere if os.environ.get("MESH", "uv") == "cube" els
 vtx, idx, mats, mids = gen(mesh_tris, seed=3)
 ext = float(np.abs(vtx).max())
 t0 = time.perf_counter()
-nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+# BUILD=host (default): the mesh's tree from the host SAH builder; host_splits: the same with
+# bvh.sah.use_splits; gpu: no tree from the caller, the library builds it on the GPU
+BUILD = os.environ.get("BUILD", "host")
+host_opts = {"bvh.builder": "sah"}
+if BUILD == "host_splits":
+    host_opts["bvh.sah.use_splits"] = "1"
+nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**host_opts))
 t_mesh = time.perf_counter() - t0
 rng = np.random.default_rng(1)
 tr = np.zeros((n_side * n_side, 3, 4), dtype=np.float32)
@@ -37,6 +43,8 @@ for k in range(n_side * n_side):
 mesh_of = [0] * (n_side * n_side)
 meshes = [(nodes, vtx, idx, None)]
 top = mipt.build_bvh(mipt.instance_bounds(meshes, tr, mesh_of))
+if BUILD == "gpu":
+    meshes = [(None, vtx, idx, None)]
 t0 = time.perf_counter()
 two = mipt.Scene.instanced(ctx, meshes, tr, mesh_of, top)
 t_two = time.perf_counter() - t0
@@ -60,7 +68,8 @@ def rate(scene, d_rays, reps=3):
     return reps * n / (time.perf_counter() - t0) / 1e6
 
 
-out = {"instances": n_side * n_side, "mesh_triangles": mesh_tris,
+out = {"instances": n_side * n_side, "mesh_triangles": mesh_tris, "mesh_tree": BUILD,
+       "mesh_leaves": (len(two.read_mesh_nodes(0)) + 1) // 2,
        "instanced_triangles": n_side * n_side * mesh_tris, "mesh_build_s": round(t_mesh, 2),
        "two_level_create_s": round(t_two, 2)}
 out["two_level_primary_mrays_s"] = rate(two, d_r)
