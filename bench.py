@@ -80,11 +80,14 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-record", action="store_true",
                     help="skip the second roofline record (28 M-triangle scene, HBM-resident traversal)")
-    ap.add_argument("--no-hbm-uniform", action="store_true",
-                    help="skip the second record's companion measurement on the uniformly tessellated surface")
-    ap.add_argument("--hbm-scene", choices=["cube", "uv"], default="uv",
+    ap.add_argument("--no-hbm-companion", "--no-hbm-uniform", dest="no_hbm_companion", action="store_true",
+                    help="skip the second record's companion measurement on the other tessellation of the surface")
+    ap.add_argument("--hbm-scene", choices=["cube", "uv"], default="cube",
                     help="tessellation of the second record's closed surface: a cube's faces pushed out to "
-                         "the sphere (uniform triangles), or latitude / longitude (two pole fans)")
+                         "the sphere (triangles of nearly uniform size, as a scanned mesh has them), or latitude "
+                         "/ longitude (two pole fans of sliver triangles); the other one is the companion")
+    ap.add_argument("--hbm-launches", type=int, default=7,
+                    help="timed launches per ray order of the second record (median reported, all listed)")
     ap.add_argument("--hbm-tris", type=int, default=28_000_000)
     ap.add_argument("--hbm-rays", type=int, default=1 << 24)
     ap.add_argument("--cpu-baseline-scale", type=int, default=1,
@@ -445,27 +448,19 @@ def main():
             if same and "counters" in tr:
                 out["roofline"]["counters_copied_from_profiles"] = tr["counters"]
         if not args.no_hbm_record and world == 1:
-            out["roofline_hbm"] = hbm_record(args, ctx, torch, mipt, scenes)
-            if live.get("trace", {}).get("FETCH_SIZE") is not None and "WRITE_SIZE" in live["trace"]:
-                h = out["roofline_hbm"]
-                h["traffic"] = traffic_bytes(live["trace"], float(args.hbm_rays)) / 1e9
-                h["traffic_source"] = ("GB per launch, measured by this run: child passes of this script under "
-                                       "rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; %d launches each)"
-                                       % live["trace"]["launches_counted"])
-                h["hbm_frac_from_traffic"] = h["traffic"] / (h["avg_launch_ms"] * 1e-3) / HBM_PEAK_GBS
-            if args.hbm_scene == "uv" and not args.no_hbm_uniform:
-                # The same surface without the pole fans.  A few rays through a fan make > 1000
-                # triangle tests each, a serial chain of milliseconds that half of every launch
-                # above waits for; a scanned mesh has no such fans.  Its upper tree levels are
-                # shared by all rays through the caches, so its reference-layout bytes per second
-                # exceed HBM peak: reported as a rate, not as a roofline fraction.
-                u = hbm_record(args, ctx, torch, mipt, scenes, kind="cube")
-                out["roofline_hbm"]["same_surface_uniform_tessellation"] = {
-                    k: u[k] for k in ("workload", "avg_launch_ms", "mrays_per_s_kernel", "mrays_per_s_call_incl_sort",
-                                      "nodes_per_ray", "tris_per_ray", "bytes_per_ray", "four_child_walk",
-                                      "queue_order", "hit_fraction", "tie_rays")}
-                out["roofline_hbm"]["same_surface_uniform_tessellation"]["algorithmic_gbs_over_hbm_peak"] = u["frac"]
-                out["roofline_hbm"]["same_surface_uniform_tessellation"]["queue_order"].pop("frac", None)
+            out["roofline_hbm"] = hbm_record(args, ctx, torch, mipt, scenes, live=live.get("trace"))
+            if not args.no_hbm_companion:
+                # The same surface in the other tessellation (latitude / longitude: at each pole
+                # thousands of sliver triangles meet in one vertex; the GPU builder puts each
+                # sliver into several leaves, without which a few rays through a fan make
+                # thousands of tests each and hold every launch for milliseconds).
+                other = "uv" if args.hbm_scene == "cube" else "cube"
+                u = hbm_record(args, ctx, torch, mipt, scenes, kind=other)
+                out["roofline_hbm"]["same_surface_other_tessellation"] = {
+                    k: u[k] for k in ("workload", "avg_launch_ms", "launch_ms", "mrays_per_s_kernel",
+                                      "mrays_per_s_call_incl_sort", "nodes_per_ray", "tris_per_ray", "bytes_per_ray",
+                                      "four_child_walk", "queue_order", "hit_fraction", "tie_rays", "tree_depth",
+                                      "leaves", "algorithmic_gbs_over_hbm_peak")}
         if link_enc != mipt.PT_LINKS_FLOAT_VALUE:
             out["cpu_baseline_skipped"] = "the CPU restatement of the renderer reads float-valued links only"
         elif not args.no_cpu_baseline and world == 1:    # the host-core baseline belongs to the 1-GPU line
@@ -503,10 +498,10 @@ def live_traffic(args, want_hbm):
     if not os.path.exists(prof):
         return {"error": "rocprofv3 not found"}
     child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-             "--no-live-counters", "--no-hbm-uniform", "--width", str(args.width), "--height", str(args.height),
+             "--no-live-counters", "--no-hbm-companion", "--width", str(args.width), "--height", str(args.height),
              "--tris", str(args.tris), "--depth", str(args.depth), "--spp-per-step", str(args.spp_per_step),
              "--samples-per-pass", str(args.samples_per_pass), "--hbm-tris", str(args.hbm_tris),
-             "--hbm-rays", str(args.hbm_rays), "--hbm-scene", args.hbm_scene]
+             "--hbm-rays", str(args.hbm_rays), "--hbm-scene", args.hbm_scene, "--hbm-launches", "3"]
     if not want_hbm:
         child.append("--no-hbm-record")
     if args.nee:
@@ -561,11 +556,17 @@ def traffic_bytes(c, rays_per_launch):
     return c["FETCH_SIZE"] * 1024.0 + 16.0 * rays_per_launch + c["WRITE_SIZE"] * 1024.0
 
 
-def hbm_record(args, ctx, torch, mipt, scenes, kind=None):
-    """The regime the bytes-per-ray formula was written for: a scene far larger than the caches
-    (28 M-triangle closed surface, 3.1 GB of traversal data, tree built on the GPU) and 2^24
-    incoherent secondary rays through pt_trace_closest_device.  achieved = algorithmic bytes
-    of the launch / device time of the traversal kernel alone, against HBM peak."""
+def hbm_record(args, ctx, torch, mipt, scenes, kind=None, live=None):
+    """The regime beyond the caches: a 28 M-triangle closed surface (3.6 GB of node and triangle
+    records, tree built on the GPU) and 2^24 incoherent secondary rays through
+    pt_trace_closest_device.  What bounds the kernel there is the rate at which the memory system
+    serves dependent 64-byte fetches scattered over gigabytes, so that is what the record prices:
+    achieved = the launch's fetches from memory (FETCH_SIZE of this run's counter passes / 64 B)
+    per second, peak = what a bare gather kernel (pt_measure_gather: same grid, same loads, no
+    arithmetic) fetches per second from a table of the scene's own footprint, measured in this
+    run.  The HBM-peak fraction of the counted traffic and the reference-layout ("algorithmic")
+    bytes are reported beside it as context.  live: {"FETCH_SIZE": KB, "WRITE_SIZE": KB,
+    "launches_counted": n} per launch of this kernel, or None."""
     t0 = time.time()
     kind = kind or args.hbm_scene
     gen = scenes.displaced_cube_sphere if kind == "cube" else scenes.displaced_sphere
@@ -580,11 +581,12 @@ def hbm_record(args, ctx, torch, mipt, scenes, kind=None):
     ctx.synchronize()
     build_s = time.perf_counter() - t0
     ctx.set_option("build.optimize_passes", 0)
+    leaves = (int(mipt.lib.pt_scene_node_count(sc._h)) + 1) // 2
     d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
     d_h = torch.empty_like(d_r)
-    # The launch is priced with the slab and triangle tests of the two-child walk of this tree
-    # (the fewer of the two forms); the four-child walk that is timed tests more child boxes
-    # (its coarse boxes admit more) and must not be credited for them.
+    # The reference-layout bytes are priced with the slab and triangle tests of the two-child walk
+    # of this tree (the fewer of the two forms); the four-child walk that is timed tests more
+    # child boxes (its coarse boxes admit more) and is not credited for them.
     ctx.set_option("extend.quad", 0)
     stc = sc.trace_closest_device_counted(d_r.data_ptr(), n, d_h.data_ptr())
     ctx.set_option("extend.quad", -1)
@@ -593,52 +595,76 @@ def hbm_record(args, ctx, torch, mipt, scenes, kind=None):
     bpr = 32.0 * n_box + 48.0 * n_tri + 64.0
     ctx.set_kernel_timing(True)
     res = {}
+    reps = max(1, args.hbm_launches)
     for name, sort in (("origin_cell_order", 1), ("queue_order", 0)):
         ctx.set_option("trace.sort_rays", sort)
         sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr())
+        first_ms = ctx.last_trace_ms()
         ctx.synchronize()
-        k_ms, reps = 0.0, 3
+        k_ms = []
         t0 = time.perf_counter()
         for _ in range(reps):
             sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr())
-            k_ms += ctx.last_trace_ms()
+            k_ms.append(ctx.last_trace_ms())
         ctx.synchronize()
-        res[name] = {"kernel_ms": k_ms / reps, "call_ms": (time.perf_counter() - t0) / reps * 1e3}
+        res[name] = {"kernel_ms": float(np.median(k_ms)), "min_ms": min(k_ms), "max_ms": max(k_ms),
+                     "first_untimed_launch_ms": first_ms, "each_ms": [round(x, 3) for x in k_ms],
+                     "call_ms": (time.perf_counter() - t0) / reps * 1e3}
     ctx.set_option("trace.sort_rays", -1)
     hit_frac = float((d_h.view(torch.int32)[:, 1] >= 0).float().mean().item())
+    depth = sc.tree_depth()
     sc.close()
+    # what this GPU fetches per second from a table as large as the scene's records, 64 bytes at a
+    # time, with nothing else to do
+    footprint = 64 * (leaves - 1) + 64 * leaves
+    gather = ctx.measure_gather(footprint, 64, 400) / 1e9
     best = res["origin_cell_order"]
-    ach = bpr * n / (best["kernel_ms"] * 1e-3) / 1e9
-    rec = {"bound": "hbm",
+    sec = best["kernel_ms"] * 1e-3
+    alg = bpr * n / sec / 1e9
+    rec = {"bound": "hbm (dependent 64 B fetches scattered over gigabytes: fetch rate, not bandwidth)",
            "kernel": "k_trace_ordered_persistent (four-child nodes with quantised boxes: the form "
                      "scenes beyond the caches are walked in); nodes_per_ray / tris_per_ray / bytes_per_ray "
                      "are those of the two-child walk of the same tree on the same rays",
-           "workload": "Lucy-class displaced closed surface (%s), %d tris (%.2f GB of node + triangle "
-                       "records), %d secondary rays (origins on the surface, cosine directions, seed 7), tree "
-                       "built on the GPU with 8 optimisation passes in %.2f s" %
-                       ("latitude / longitude tessellation: two pole fans of thousands of sliver triangles" if kind == "uv"
+           "workload": "Lucy-class displaced closed surface (%s), %d tris in %d leaves (%.2f GB of 64-byte node "
+                       "and triangle records), %d secondary rays (origins on the surface, cosine directions, "
+                       "seed 7), tree built on the GPU with 8 optimisation passes in %.2f s" %
+                       ("latitude / longitude tessellation: two pole fans of thousands of sliver triangles, each "
+                        "sliver cut into several leaves" if kind == "uv"
                         else "cube faces pushed out to the sphere: triangles of nearly uniform size",
-                        idx.shape[0], (64.0 * (idx.shape[0] - 1) + 48.0 * idx.shape[0]) / 1e9, n, build_s),
-           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-           "traffic": None, "launches": 3, "avg_launch_ms": best["kernel_ms"],
+                        idx.shape[0], leaves, footprint / 1e9, n, build_s),
+           "achieved": None, "peak": gather, "unit": "Gfetches/s", "frac": None, "traffic": None,
+           "peak_source": "pt_measure_gather on a %.2f GB table (the scene's footprint), this run" % (footprint / 1e9),
+           "launches": reps, "avg_launch_ms": best["kernel_ms"],
+           "launch_ms": {k: best[k] for k in ("min_ms", "max_ms", "first_untimed_launch_ms", "each_ms")},
            "nodes_per_ray": n_box, "tris_per_ray": n_tri, "bytes_per_ray": bpr,
            "four_child_walk": {"child_boxes_tested_per_ray": stq.box_tests / n,
                                "tris_per_ray": stq.tri_tests / n},
-           "algorithmic_gb_per_launch": bpr * n / 1e9,
+           "algorithmic_gb_per_launch": bpr * n / 1e9, "algorithmic_gbs": alg,
+           "algorithmic_gbs_over_hbm_peak": alg / HBM_PEAK_GBS,
+           "note": "algorithmic bytes are reference-layout bytes (32 B per box test, 48 B per triangle test, 64 B "
+                   "per ray); the caches serve the upper levels of the tree, so their ratio to HBM peak is context, "
+                   "not the fraction",
            "mrays_per_s_kernel": n / best["kernel_ms"] / 1e3,
            "mrays_per_s_call_incl_sort": n / best["call_ms"] / 1e3,
            "queue_order": {"avg_launch_ms": res["queue_order"]["kernel_ms"],
-                           "mrays_per_s": n / res["queue_order"]["kernel_ms"] / 1e3,
-                           "frac": bpr * n / (res["queue_order"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-           "hit_fraction": hit_frac, "tie_rays": int(stc.tie_rays), "scene_and_rays_generated_s": round(gen_s, 1)}
-    tpath = os.path.join(REPO, "profiles", "r02_traffic_hbm.json")
-    if os.path.exists(tpath) and (args.hbm_tris, n, kind) == (28_000_000, 1 << 24, "uv"):
-        with open(tpath) as f:
-            tr = json.load(f)
-        rec["traffic"] = tr["traffic_bytes_per_launch"] / 1e9
-        rec["traffic_source"] = ("GB per launch, copied from profiles/r02_traffic_hbm.json (rocprofv3 --pmc passes; "
-                                 "FETCH_SIZE calibrated there on 64-byte gathers of known size), not measured by this run")
-        rec["hbm_frac_from_traffic"] = rec["traffic"] / (best["kernel_ms"] * 1e-3) / HBM_PEAK_GBS
+                           "launch_ms": {k: res["queue_order"][k] for k in ("min_ms", "max_ms",
+                                                                            "first_untimed_launch_ms", "each_ms")},
+                           "mrays_per_s": n / res["queue_order"]["kernel_ms"] / 1e3},
+           "hit_fraction": hit_frac, "tie_rays": int(stc.tie_rays), "tree_depth": depth, "leaves": leaves,
+           "scene_and_rays_generated_s": round(gen_s, 1)}
+    if live and live.get("FETCH_SIZE") is not None and "WRITE_SIZE" in live:
+        fetches = live["FETCH_SIZE"] * 1024.0 / 64.0
+        rec["achieved"] = fetches / sec / 1e9
+        rec["frac"] = rec["achieved"] / gather
+        rec["achieved_source"] = ("FETCH_SIZE of this run's rocprofv3 --pmc child pass over the same kernel (%d launches), "
+                                  "in 64-byte fetches, / the median launch time" % live["launches_counted"])
+        rec["traffic"] = traffic_bytes(live, float(n)) / 1e9
+        rec["traffic_source"] = ("GB per launch, measured by this run: child passes of this script under "
+                                 "rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; %d launches each)" % live["launches_counted"])
+        rec["hbm_frac_from_traffic"] = rec["traffic"] / sec / HBM_PEAK_GBS
+    else:
+        rec["achieved_source"] = ("no counter pass in this run (rocprofv3 missing, --no-live-counters, or a companion "
+                                  "measurement): fetch rate not measured; see profiles/ for the committed passes")
     return rec
 
 

@@ -73,6 +73,41 @@ for radius, passes in ((0, 16), (8, 0)):
 ctx.set_option("build.ploc_radius", 0)
 ctx.set_option("build.optimize_passes", 0)
 
+# (a4) triangles in several leaves and ties together: a latitude / longitude surface (two pole fans
+# of slivers, cut into up to 64 leaves each by the GPU builder) with a twentieth of its triangles
+# and every tenth sliver of the fans twice; rays at the surface and rays aimed at the fans.  The
+# same mesh through the host builder with spatial splits.
+vtx, idx, _, _ = scenes.displaced_sphere(1_000_000, seed=7)
+fan = np.nonzero(np.abs(vtx[idx][:, :, 1]).max(axis=1) > 0.999 * np.abs(vtx[:, 1]).max())[0]
+idxf = np.concatenate([idx, idx[np.random.default_rng(6).choice(idx.shape[0], idx.shape[0] // 20, replace=False)],
+                       idx[fan[::10]]])
+m = min(n, 1 << 21)
+raysf = scenes.surface_rays(vtx, idx, m, seed=17 + OFF).astype(mipt.ray_dtype)
+aim = scenes.surface_rays(vtx, idx[fan], m // 4, seed=18 + OFF).astype(mipt.ray_dtype)
+aim["o"][:, :3] -= 0.5 * aim["d"][:, :3]            # start off the surface, towards and through the fans
+aim["d"][:, :3] *= np.where(np.random.default_rng(19 + OFF).random((len(aim), 1)) < 0.5, 1, -1).astype(np.float32)
+raysf = np.concatenate([raysf, aim])
+for passes in (0, 8):
+    ctx.set_option("build.optimize_passes", passes)
+    sc = mipt.Scene(ctx, None, vtx, idxf)
+    nodes = sc.read_nodes()
+    leaves = (len(nodes) + 1) // 2
+    bad += compare(f"sphere 1 M with pole fans + duplicates, GPU tree with split leaves ({leaves} leaves, {passes} passes)",
+                   sc, nodes, vtx, idxf, raysf, False)
+    ra = raysf.copy()
+    ra["o"][:, 3] = np.random.default_rng(8).uniform(0.01, 1.0, len(ra)).astype(np.float32)
+    d_any = int((sc.trace_any(ra) != oracle.any_hit(nodes, vtx, idxf, ra, nthreads=16)).sum())
+    print(json.dumps({"case": "  the same tree, occlusion", "rays": len(ra), "differing": d_any}), flush=True)
+    bad += d_any
+    sc.close()
+ctx.set_option("build.optimize_passes", 0)
+nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idxf), mipt.bvh_options(**{"bvh.builder": "sah", "bvh.sah.use_splits": "1",
+                                                                          "bvh.sah.min_overlap": "0.0001"}))
+sc = mipt.Scene(ctx, nodes, vtx, idxf)
+bad += compare(f"the same mesh, host SAH tree with spatial splits ({(len(nodes) + 1) // 2} leaves)", sc, nodes, vtx, idxf,
+               raysf, False)
+sc.close()
+
 # (b1) optional: a 9 M-triangle tree (18 M nodes, integer links) built and optimised on the GPU:
 # structure checked on the host, a sample of rays against the restatement walking that tree
 if len(sys.argv) > 2 and sys.argv[2] == "big":
