@@ -486,6 +486,11 @@ int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
 
 int pt_context_destroy(pt_context *ctx) {
     if (!ctx) return PT_OK;
+    // a communicator uses its context's device and stream until it is destroyed
+    if (ctx->live_comms.load() > 0)
+        return fail(PT_ERR_INVALID, "pt_context_destroy: " + std::to_string(ctx->live_comms.load()) +
+                                        " communicator(s) of this context are still alive: "
+                                        "pt_comm_destroy them first");
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->release_all();

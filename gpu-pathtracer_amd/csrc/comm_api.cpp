@@ -147,6 +147,7 @@ int pt_comm_create(pt_context *ctx, const void *id, int n_ranks, int rank, pt_co
     c->rank = rank;
     c->size = n_ranks;
     NCCL_CHECK(r.CommInitRank(&c->comm, n_ranks, u, rank));
+    ctx->live_comms.fetch_add(1);
     *out = c.release();
     return PT_OK;
 }
@@ -172,6 +173,7 @@ int pt_comm_create_all(pt_context *const *ctxs, int n, pt_comm **out) {
         c->comm = comms[(size_t)i];
         c->rank = i;
         c->size = n;
+        ctxs[i]->live_comms.fetch_add(1);
         out[i] = c;
     }
     return PT_OK;
@@ -186,6 +188,7 @@ int pt_comm_destroy(pt_comm *comm) {
     (void)hipStreamSynchronize(comm->ctx->stream);
     if (comm->comm) (void)rccl().CommDestroy(comm->comm);
     comm->staging.release();
+    comm->ctx->live_comms.fetch_sub(1);
     delete comm;
     return PT_OK;
 }

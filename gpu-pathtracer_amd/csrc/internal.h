@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -69,6 +70,7 @@ struct pt_context {
     std::vector<hipEvent_t> events;     // pool for per-kernel timing
     hipEvent_t trace_events[2] = {nullptr, nullptr};   // around the last trace call's kernel
     bool trace_timed = false;
+    std::atomic<int> live_comms{0};     // pt_comm objects made on this context and not yet destroyed
 
     void release_all() {
         render_counts.release();

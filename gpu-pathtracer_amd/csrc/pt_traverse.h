@@ -207,10 +207,12 @@ __device__ __forceinline__ void replay_candidates(const DeviceScene &s, const fl
     auto leaf = [&](int32_t node, int32_t tri) {
         const float4 lo = s.nodes[2 * (int64_t)node + 0];
         const float4 hi = s.nodes[2 * (int64_t)node + 1];
-        float t0, e0;
+        // entered within the ray's reach at all?  then also within the current distance iff the
+        // entry lies before it (the slab test's far side does not depend on the distance)
+        float e0;
         if (!intersect_box(r, lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, ro.w, e0)) return;
         latest_entry = fmaxf(latest_entry, e0);
-        if (!intersect_box(r, lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, tbest, t0)) return;
+        if (!(tbest >= e0)) return;
         const int32_t i0 = s.idx[3 * (int64_t)tri + 0], i1 = s.idx[3 * (int64_t)tri + 1],
                       i2 = s.idx[3 * (int64_t)tri + 2];
         const float *p0 = s.vtx + 3 * (int64_t)i0, *p1 = s.vtx + 3 * (int64_t)i1,
@@ -241,13 +243,10 @@ __device__ __forceinline__ void replay_candidates(const DeviceScene &s, const fl
         while (ia < ea || ib < eb) {                 // the two ascending lists, merged
             const int32_t na = ia < ea ? s.tri_leaf_list[ia] : INT_MAX;
             const int32_t nb = ib < eb ? s.tri_leaf_list[ib] : INT_MAX;
-            if (na < nb) {
-                leaf(na, pa);
-                ++ia;
-            } else {
-                leaf(nb, pb);
-                ++ib;
-            }
+            const bool take_a = na < nb;
+            ia += take_a ? 1u : 0u;
+            ib += take_a ? 0u : 1u;
+            leaf(take_a ? na : nb, take_a ? pa : pb);
         }
     }
     if (!(latest_entry <= tbest + tbest * PT_TIE_WINDOW)) {

@@ -435,8 +435,9 @@ class Context:
         return out.value
 
     def close(self) -> None:
+        """pt_context_destroy; raises while a Comm of this context is still open."""
         if self._h:
-            lib.pt_context_destroy(self._h)
+            _check(lib.pt_context_destroy(self._h))
             self._h = _vp()
 
     def __del__(self):

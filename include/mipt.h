@@ -247,6 +247,8 @@ int pt_context_set_option(pt_context *ctx, const char *key, const char *value);
  * set lies there.  Allocates and frees the table; blocking. */
 int pt_measure_gather(pt_context *ctx, uint64_t table_bytes, uint32_t record_bytes,
                       uint32_t iterations, double *records_per_s);
+/* Fails with PT_ERR_INVALID, and destroys nothing, while a pt_comm made on the context is alive
+ * (a communicator uses its context's device and stream until pt_comm_destroy). */
 int pt_context_destroy(pt_context *ctx);
 
 /* init_device_data, src/main_granite.cpp:180-194: uploads the three storage buffers the

@@ -46,6 +46,21 @@ def test_one_rank_communicator_by_unique_id(mipt, scenes, gpu_ctx):
         mipt.Comm(gpu_ctx, uid, 2, 2)                   # rank outside the communicator
 
 
+def test_context_outlives_its_communicators(mipt):
+    """A communicator uses its context's device and stream until it is destroyed: the context
+    refuses to go first."""
+    ctx = mipt.Context(0)
+    comm = mipt.Comm(ctx, mipt.comm_unique_id(), 1, 0)
+    with pytest.raises(mipt.MiptError, match="communicator"):
+        ctx.close()
+    film = mipt.Film(ctx, 32, 32)
+    comm.reduce_film(film, root=0)                      # the context is still whole
+    ctx.synchronize()
+    film.close()
+    comm.close()
+    ctx.close()
+
+
 def test_one_process_communicators(mipt, scenes, gpu_ctx):
     """pt_comm_create_all: what examples/ptrender.cpp --gpus N uses."""
     handles = (C.c_void_p * 1)(gpu_ctx._h)
