@@ -113,6 +113,42 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert d["value"] is None and d["n_gpus"] == n and "visible" in d["error"]
 
 
+@pytest.mark.parametrize("kind", ["obj", "glb", "scene_dir"])
+def test_bench_renders_a_scene_file(tmp_path, kind):
+    """--scene FILE (or PT_SCENE_DIR holding sponza.*): the benchmark renders the asset through
+    pt_obj_load / pt_gltf_load, the loaders standing in for tinyobj (src/main.cpp:852-899) and
+    Granite's scene loader (src/main_granite.cpp:265-298), and says so in its line."""
+    import shutil
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("PT_SCENE_DIR", None)
+    args = []
+    if kind == "obj":
+        path = os.path.join(REPO, "tests", "golden", "cornell_box.obj")
+        args = ["--scene", path]
+    elif kind == "glb":
+        import test_gltf
+        path = str(test_gltf._document(tmp_path, "glb")[0])
+        args = ["--scene", path]
+    else:
+        d = tmp_path / "assets"
+        d.mkdir()
+        for ext in ("obj", "mtl"):
+            shutil.copy(os.path.join(REPO, "tests", "golden", "cornell_box." + ext), d / ("sponza." + ext if ext == "obj" else "cornell_box.mtl"))
+        path = str(d / "sponza.obj")
+        env["PT_SCENE_DIR"] = str(d)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--width", "160",
+           "--height", "90", "--spp-per-step", "4", "--no-hbm-record", "--no-cpu-baseline", "--no-live-counters"] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["data"] == "file" and os.path.basename(path) in d["config"]["workload"]
+    assert d["value"] > 0 and abs(d["config"]["samples_per_pixel_total"] - 8.0) < 1e-6
+    assert d["mean_radiance"] > 0
+
+
 def test_bench_measures_hbm_traffic_itself(tmp_path):
     """roofline.traffic of a default run is not copied from a file: the benchmark runs itself again
     under rocprofv3 --pmc (one counter per pass) and reports the bytes those passes counted."""

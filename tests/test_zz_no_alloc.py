@@ -84,3 +84,48 @@ def test_static_entry_point_uses_its_stack_slots(mipt, oracle, scenes, gpu_ctx):
             assert len(same_hits(got, want)) == 0
     finally:
         sc.close()
+
+
+def test_static_entry_point_under_graph_capture(mipt, oracle, scenes, gpu_ctx):
+    """What the entry point is for: a caller that may not allocate.  After one ordinary call (the
+    first call on a kernel asks the runtime for its occupancy, which cannot be captured) a
+    second call is captured into a HIP graph on the context's stream and replayed twice; every
+    replay gives the oracle's hits.  Single-level and two-level scenes."""
+    import torch
+    import two_level_util as tl
+    from test_gpu_two_level import _build
+    vtx, idx, mats, mids = scenes.atrium(65536, seed=42)
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+    flat = mipt.Scene(gpu_ctx, nodes, vtx, idx, mats, mids)
+    flat_rays = scenes.surface_rays(vtx, idx, 100000, seed=21)
+    flat_want = oracle.closest(nodes, vtx, idx, flat_rays, nthreads=8)
+    tsc = tl.scene()
+    t, two = _build(mipt, oracle, gpu_ctx, tsc)
+    two_rays = tl.rays_for(50000, 6, mipt.ray_dtype)
+    two_want = t.closest(two_rays, nthreads=8)
+    stream = torch.cuda.Stream()
+    try:
+        gpu_ctx.set_stream(stream.cuda_stream)
+        for sc, rays, want in ((flat, flat_rays, flat_want), (two, two_rays, two_want)):
+            n = len(rays)
+            d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8).copy()).cuda()
+            d_h = torch.full_like(d_r, -7.0)
+            torch.cuda.synchronize()
+            sc.trace_closest_device_static(d_r.data_ptr(), n, d_h.data_ptr())      # the warming call
+            gpu_ctx.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                sc.trace_closest_device_static(d_r.data_ptr(), n, d_h.data_ptr())
+            for _ in range(2):
+                d_h.fill_(-7.0)
+                torch.cuda.synchronize()
+                graph.replay()
+                torch.cuda.synchronize()
+                got = d_h.cpu().numpy().view(mipt.hit_dtype).reshape(-1)
+                assert len(same_hits(got, want, nan_equal=True)) == 0
+            del graph
+    finally:
+        gpu_ctx.synchronize()
+        gpu_ctx.set_stream(None)                       # back to the context's own stream
+        flat.close()
+        two.close()
