@@ -139,7 +139,7 @@ ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bo
     // 12.3 / 13.8 -> 11.1 / 11.9 ms; the bench scene, in the caches, loses 7 %).  A step pushes up to
     // three children, so the LDS goes to the stacks rather than to a copy of the top, and the
     // rays in flight no longer need thinning out: five workgroups per compute unit again.
-    if (d.qnodes && !two_level && !d.big)
+    if (d.qnodes && !two_level)
         c.quad = ctx->extend_quad >= 0 ? (ctx->extend_quad ? 1 : 0) : (beyond_caches ? 1 : 0);
     if (c.quad && beyond_caches) {
         stack = coherent ? PT_LDS_STACK_ENTRIES : 24;
@@ -528,9 +528,12 @@ static int attach_top_cache(pt_context *ctx, pt_scene *sc) {
 // be made for (a bound that is not finite, no memory) simply keeps the two-child form only.
 static int attach_quad(pt_context *ctx, pt_scene *sc) {
     DeviceScene &d = sc->dev;
-    if (!ctx->scene_quad || d.n_wnodes < 1 || d.n_tri < 2 || d.big || d.tlas) return PT_OK;
+    if (!ctx->scene_quad || d.n_wnodes < 1 || d.n_tri < 2 || d.tlas) return PT_OK;
     const size_t n_leaves = (size_t)d.n_wnodes + 1;
-    if (needs_big_addresses(d.n_wnodes, n_leaves * 4 / PT_TRI_RECORD_16B + 1)) return PT_OK;
+    // a leaf is named by its record's position in 16-byte units (four per record) in 31 bits;
+    // records beyond 4 GiB take the kernels with 64-bit addresses, like the two-child form
+    if (4 * n_leaves >= (1ull << 31)) return PT_OK;
+    if (!d.big && needs_big_addresses(d.n_wnodes, n_leaves * 4 / PT_TRI_RECORD_16B + 1)) d.big = 1;
     const size_t node_bytes = 64 * (size_t)d.n_wnodes, tri_bytes = 64 * n_leaves;
     const size_t cache_bytes = 64 * (size_t)kNodeCacheMax, index_bytes = 4 * (size_t)kNodeCacheMax;
     void *qn = nullptr, *qt = nullptr, *top = nullptr;

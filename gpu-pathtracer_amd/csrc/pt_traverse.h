@@ -273,12 +273,16 @@ __device__ __forceinline__ const float4 *wide_tri(const DeviceScene &s, int32_t 
                                             ((uint32_t)(~leaf) << 4));
 }
 
-// Records of the four-child form (scenes below 4 GiB of records only: 32-bit byte offsets).
+// Records of the four-child form, addressed like the two-child ones (BIG: 64-bit arithmetic).
+template <bool BIG = false>
 __device__ __forceinline__ const float4 *quad_node(const DeviceScene &s, int32_t node) {
+    if (BIG) return s.qnodes + 4 * (size_t)(uint32_t)node;
     return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.qnodes) +
                                             ((uint32_t)node << 6));
 }
+template <bool BIG = false>
 __device__ __forceinline__ const float4 *quad_tri(const DeviceScene &s, int32_t leaf) {
+    if (BIG) return s.qtris + (size_t)(uint32_t)(~leaf);
     return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.qtris) +
                                             ((uint32_t)(~leaf) << 4));
 }
@@ -476,7 +480,8 @@ __device__ __forceinline__ void any_begin(OrderedState &st, const float4 ro, con
 // only divergent regions are the stack accesses and the work inside the triangle test.
 // ANY: occlusion query -- the triangle step is the Moller-Trumbore test of
 // shaders/RadeonRays/bvh.glslh:289-310 and the first hit ends the ray.
-// QUAD: the node step reads a four-child node (DeviceScene::qnodes): child boxes from 8-bit
+// QUAD: the node step reads a four-child node (DeviceScene::qnodes; closest hits and occlusion
+// queries alike): child boxes from 8-bit
 // offsets on the node's grid, never inside the exact boxes, so a ray that reaches a leaf in the
 // two-child tree reaches it here too; the slab arithmetic on them is the reference's (rounding
 // is monotonic in the box).  The leaf's exact box, the one the reference tests, comes with the
@@ -504,7 +509,6 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
         while (mode == 0) {
             if constexpr (QUAD) {
               if (at_node) {
-                static_assert(!(QUAD && (ANY || BIG)), "four-child nodes: closest hits, 32-bit offsets");
                 float4 f0, f1, f2;
                 int4 ch;
                 if (CACHE && st.cur >= kLdsNodeBase) {
@@ -515,7 +519,7 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                                    __float_as_int(cw.w));
                     if (COUNT && nl) *nl += 4;
                 } else {
-                    const float4 *np = quad_node(s, st.cur);
+                    const float4 *np = quad_node<BIG>(s, st.cur);
                     f0 = np[0]; f1 = np[1]; f2 = np[2];
                     ch = reinterpret_cast<const int4 *>(np)[3];
                 }
@@ -629,7 +633,7 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
         }
         if (mode == 2) return;
         if (at_leaf) {
-            const float4 *tp = QUAD ? quad_tri(s, st.cur) : wide_tri<BIG>(s, st.cur);
+            const float4 *tp = QUAD ? quad_tri<BIG>(s, st.cur) : wide_tri<BIG>(s, st.cur);
             const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
             bool in_leaf_box = true;
             if constexpr (QUAD) {
@@ -649,9 +653,12 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                 float m1, m2, temp;
                 moller_trumbore(st.r.ox, st.r.oy, st.r.oz, st.r.sx, st.r.sy, st.r.sz, q0.x, q0.y,
                                 q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, m1, m2, temp);
+                // (four-child nodes: the reference gets to this triangle only through its leaf's own
+                // box, which the coarse boxes on the way here stand in for)
                 const bool hit = !((m1 < -PT_MT_EPS) | (m1 > 1.f + PT_MT_EPS) | (m2 < -PT_MT_EPS) |
                                    (m1 + m2 > 1.f + PT_MT_EPS) | (temp < -PT_MT_EPS) |
-                                   (temp > st.tmax + PT_MT_EPS));               // :301
+                                   (temp > st.tmax + PT_MT_EPS)) &               // :301
+                                 in_leaf_box;
                 st.primid = hit ? 0 : st.primid;
                 --st.sp;
                 const int32_t popped = stack[st.sp * kTraceBlock];

@@ -282,11 +282,11 @@ __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_two_
 }
 
 // Persistent waves with lane refill and step voting, as the closest-hit kernel.
-template <bool CACHE, bool BIG>
+template <bool CACHE, bool BIG, bool QUAD = false>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_persistent(
     DeviceScene s, RenderWorkspace ws, const unsigned int *count, PersistentParams pp) {
-    persistent_traverse<false, true, CACHE, BIG>(s, ws.shadow_rays, *count, true, pp, nullptr, nullptr,
-                                            ShadowSink{ws.shadow_carry, ws.radiance});
+    persistent_traverse<false, true, CACHE, BIG, ShadowSink, QUAD>(s, ws.shadow_rays, *count, true, pp, nullptr,
+                                                                  nullptr, ShadowSink{ws.shadow_carry, ws.radiance});
 }
 
 // PT_RENDER_DEPTH_GREY: the reference's per-pixel output (shaders/depth.frag:90-107).
@@ -379,13 +379,14 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
             k_pt_extend_persistent<false, true, false>,  k_pt_extend_persistent<false, true, true>,
             k_pt_extend_persistent<true, false, false>,  k_pt_extend_persistent<true, false, true>,
             k_pt_extend_persistent<true, true, false>,   k_pt_extend_persistent<true, true, true>};
-        // the same over the four-child nodes (scenes that have them; never with 64-bit addresses)
-        static const K quad_table[4] = {
-            k_pt_extend_persistent<false, false, false, true>, k_pt_extend_persistent<false, true, false, true>,
-            k_pt_extend_persistent<true, false, false, true>,  k_pt_extend_persistent<true, true, false, true>};
-        const bool quad = cfg.quad && s.qnodes && !s.big;
-        const K k = quad ? quad_table[(work ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)]
-                         : table[(work ? 4 : 0) | (pp.cache_nodes > 0 ? 2 : 0) | (s.big ? 1 : 0)];
+        // the same over the four-child nodes (scenes that have them)
+        static const K quad_table[8] = {
+            k_pt_extend_persistent<false, false, false, true>, k_pt_extend_persistent<false, false, true, true>,
+            k_pt_extend_persistent<false, true, false, true>,  k_pt_extend_persistent<false, true, true, true>,
+            k_pt_extend_persistent<true, false, false, true>,  k_pt_extend_persistent<true, false, true, true>,
+            k_pt_extend_persistent<true, true, false, true>,   k_pt_extend_persistent<true, true, true, true>};
+        const bool quad = cfg.quad && s.qnodes;
+        const K k = (quad ? quad_table : table)[(work ? 4 : 0) | (pp.cache_nodes > 0 ? 2 : 0) | (s.big ? 1 : 0)];
         launch_persistent(k, st, blocks(max_rays, kBlock), cfg, pp, s, (const pt_ray *)ws.rays[buf], ws.hits, count,
                           tie_count, work, pp);
         return;
@@ -424,10 +425,14 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
     }
     if (cfg.persistent_blocks > 0 && s.n_tri >= 2) {
         using K = void (*)(DeviceScene, RenderWorkspace, const unsigned int *, PersistentParams);
-        static const K table[4] = {k_pt_occlude_persistent<false, false>, k_pt_occlude_persistent<false, true>,
-                                   k_pt_occlude_persistent<true, false>, k_pt_occlude_persistent<true, true>};
-        launch_persistent(table[(pp.cache_nodes > 0 ? 2 : 0) | (s.big ? 1 : 0)], st, blocks(max_rays, kBlock), cfg,
-                          pp, s, ws, shadow_count, pp);
+        static const K table[8] = {
+            k_pt_occlude_persistent<false, false>, k_pt_occlude_persistent<false, true>,
+            k_pt_occlude_persistent<true, false>, k_pt_occlude_persistent<true, true>,
+            k_pt_occlude_persistent<false, false, true>, k_pt_occlude_persistent<false, true, true>,
+            k_pt_occlude_persistent<true, false, true>, k_pt_occlude_persistent<true, true, true>};
+        const bool quad = cfg.quad && s.qnodes;
+        launch_persistent(table[(quad ? 4 : 0) | (pp.cache_nodes > 0 ? 2 : 0) | (s.big ? 1 : 0)], st,
+                          blocks(max_rays, kBlock), cfg, pp, s, ws, shadow_count, pp);
         return;
     }
     hipLaunchKernelGGL(k_pt_occlude, dim3(blocks(max_rays, kBlock)), dim3(kBlock), 0, st, s, ws,

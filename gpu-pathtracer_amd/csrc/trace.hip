@@ -100,10 +100,11 @@ struct OccludedSink {
         out[ray] = occluded ? 1 : 0;
     }
 };
-template <bool CACHE, bool BIG>
+template <bool CACHE, bool BIG, bool QUAD = false>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_persistent(
     DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, PersistentParams pp) {
-    persistent_traverse<false, true, CACHE, BIG>(s, rays, n, true, pp, nullptr, nullptr, OccludedSink{occluded});
+    persistent_traverse<false, true, CACHE, BIG, OccludedSink, QUAD>(s, rays, n, true, pp, nullptr, nullptr,
+                                                                    OccludedSink{occluded});
 }
 
 // Two-level scenes: one thread per ray (see closest_hit_two_level).
@@ -569,13 +570,14 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
             k_trace_ordered_persistent<false, true, false>,  k_trace_ordered_persistent<false, true, true>,
             k_trace_ordered_persistent<true, false, false>,  k_trace_ordered_persistent<true, false, true>,
             k_trace_ordered_persistent<true, true, false>,   k_trace_ordered_persistent<true, true, true>};
-        // the same over the four-child nodes (scenes that have them; never with 64-bit addresses)
-        static const K quad_table[4] = {
-            k_trace_ordered_persistent<false, false, false, true>, k_trace_ordered_persistent<false, true, false, true>,
-            k_trace_ordered_persistent<true, false, false, true>,  k_trace_ordered_persistent<true, true, false, true>};
-        const bool quad = cfg.quad && s.qnodes && !s.big;
-        const K k = quad ? quad_table[(count_work ? 2 : 0) | (cached ? 1 : 0)]
-                         : table[(count_work ? 4 : 0) | (cached ? 2 : 0) | (s.big ? 1 : 0)];
+        // the same over the four-child nodes (scenes that have them)
+        static const K quad_table[8] = {
+            k_trace_ordered_persistent<false, false, false, true>, k_trace_ordered_persistent<false, false, true, true>,
+            k_trace_ordered_persistent<false, true, false, true>,  k_trace_ordered_persistent<false, true, true, true>,
+            k_trace_ordered_persistent<true, false, false, true>,  k_trace_ordered_persistent<true, false, true, true>,
+            k_trace_ordered_persistent<true, true, false, true>,   k_trace_ordered_persistent<true, true, true, true>};
+        const bool quad = cfg.quad && s.qnodes;
+        const K k = (quad ? quad_table : table)[(count_work ? 4 : 0) | (cached ? 2 : 0) | (s.big ? 1 : 0)];
         if (bracket) (void)hipEventRecord(bracket[0], st);
         launch_persistent(k, st, grid_for(n), cfg, pp, s, rays, hits, (uint32_t)n, fixup, pp, counters, perm);
         if (bracket) (void)hipEventRecord(bracket[1], st);
@@ -610,10 +612,14 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
     if (wide && cfg.persistent_blocks > 0) {
         const PersistentParams pp = persistent_params(cfg, s);
         using K = void (*)(DeviceScene, const pt_ray *, int32_t *, uint32_t, PersistentParams);
-        static const K table[4] = {k_trace_any_persistent<false, false>, k_trace_any_persistent<false, true>,
-                                   k_trace_any_persistent<true, false>, k_trace_any_persistent<true, true>};
-        launch_persistent(table[(pp.cache_nodes > 0 ? 2 : 0) | (s.big ? 1 : 0)], st, grid_for(n), cfg, pp, s, rays,
-                          occluded, (uint32_t)n, pp);
+        static const K table[8] = {
+            k_trace_any_persistent<false, false>, k_trace_any_persistent<false, true>,
+            k_trace_any_persistent<true, false>, k_trace_any_persistent<true, true>,
+            k_trace_any_persistent<false, false, true>, k_trace_any_persistent<false, true, true>,
+            k_trace_any_persistent<true, false, true>, k_trace_any_persistent<true, true, true>};
+        const bool quad = cfg.quad && s.qnodes;
+        launch_persistent(table[(quad ? 4 : 0) | (pp.cache_nodes > 0 ? 2 : 0) | (s.big ? 1 : 0)], st, grid_for(n), cfg,
+                          pp, s, rays, occluded, (uint32_t)n, pp);
         return;
     }
     hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays, occluded, n,

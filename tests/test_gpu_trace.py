@@ -42,6 +42,23 @@ def _check_all_modes(mipt, oracle, ctx, nodes, vtx, idx, rays, expect_ties=None,
         bad = same_hits(quad, want, nan_equal)
         assert len(bad) == 0, (f"four-child traversal differs from the oracle on {len(bad)} of "
                                f"{len(rays)} rays, first {bad[:8]}: {quad[bad[:3]]} vs {want[bad[:3]]}")
+        # occlusion queries (IntersectSceneAny) on the same rays, their reach set around the
+        # nearest hit so that some are blocked and some are not: two-child and four-child walk
+        ra = rays.copy()
+        t = want["uvwt"][:, 3]
+        hit = (want["primid"] >= 0) & np.isfinite(t)
+        scale = np.random.default_rng(len(rays)).uniform(0.5, 1.5, len(rays)).astype(np.float32)
+        ra["o"][hit, 3] = t[hit] * scale[hit]
+        want_any = oracle.any_hit(nodes, vtx, idx, ra, nthreads=8)
+        for q in (0, 1):
+            ctx.set_option("extend.quad", q)
+            try:
+                got_any = sc.trace_any(ra)
+            finally:
+                ctx.set_option("extend.quad", -1)
+            bad = np.nonzero(got_any != want_any)[0]
+            assert len(bad) == 0, (f"occlusion ({'four' if q else 'two'}-child walk) differs from the oracle on "
+                                   f"{len(bad)} of {len(rays)} rays, first {bad[:8]}")
         return got, st
     finally:
         sc.close()
