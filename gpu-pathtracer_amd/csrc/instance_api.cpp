@@ -466,6 +466,29 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             d.wtop = (const float4 *)dst;
             d.top_root = (uint32_t)tot_wnodes;
         }
+        if (n_instances >= 2) {
+            // the top of the top-level tree, which every ray walks first, as the persistent
+            // kernels copy it to LDS (same layout as a single-level scene's)
+            const size_t node_bytes = 64 * (size_t)kNodeCacheMax, index_bytes = 4 * (size_t)kNodeCacheMax;
+            char *buf = (char *)dev_alloc(node_bytes + index_bytes + 16);
+            int32_t *index = reinterpret_cast<int32_t *>(buf + node_bytes);
+            uint32_t *n_dev = reinterpret_cast<uint32_t *>(buf + node_bytes + index_bytes);
+            hipError_t err = hipDeviceSynchronize();            // the uploads above used the null stream
+            uint32_t n_cached = 0;
+            if (err == hipSuccess) {
+                launch_build_top_cache(ctx->stream, d.wnodes, (uint32_t)(tot_wnodes + top_room), (float4 *)buf, index,
+                                       n_dev, d.top_root);
+                err = hipMemcpyAsync(&n_cached, n_dev, 4, hipMemcpyDeviceToHost, ctx->stream);
+            }
+            if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+            if (err != hipSuccess) {
+                sc->release();
+                return hip_fail(err, "pt_scene_create_instanced: top-level cache");
+            }
+            d.top_cache = (const float4 *)buf;
+            d.top_global = index;
+            d.n_top_cache = n_cached;
+        }
         d.instances = (const DeviceInstance *)upload(dinst.data(), sizeof(DeviceInstance) * dinst.size());
         d.n_tlas_nodes = n_top_nodes;
         d.n_instances = n_instances;

@@ -46,8 +46,8 @@ struct DeviceScene {
     uint32_t link_enc;
     uint32_t wide_depth;
     uint32_t big;          // wnodes or wtris reach beyond 4 GiB: records need 64-bit addresses
-    // Single-level scenes: the first n_top_cache two-child nodes in breadth-first order from the
-    // root, as the persistent kernels copy them to LDS.  A child that lies in this array itself
+    // The first n_top_cache two-child nodes in breadth-first order from the root (of a two-level
+    // scene: from the top-level root, wnodes[top_root]), as the persistent kernels copy them to LDS.  A child that lies in this array itself
     // is named kLdsNodeBase + its position here; other children as in wnodes.
     const float4 *top_cache;
     const int32_t *top_global;   // index in wnodes of each node of top_cache
@@ -108,8 +108,9 @@ inline bool needs_big_addresses(uint64_t n_wnodes, uint64_t n_wtris) {
 constexpr int kNodeCacheMax = PT_LDS_NODE_CACHE_MAX;
 // Fills top_cache and top_global (room for kNodeCacheMax nodes each) from wnodes and writes the
 // number of nodes to *n_out.
+// root: the node to start from (0; the top-level root of a two-level scene).
 void launch_build_top_cache(hipStream_t st, const float4 *wnodes, uint32_t n_wnodes, float4 *cache,
-                            int32_t *global_index, uint32_t *n_out);
+                            int32_t *global_index, uint32_t *n_out, uint32_t root = 0);
 // Folds the two-child nodes into four-child nodes with quantised child boxes and writes the
 // triangle records with their leaves' boxes (DeviceScene::qnodes / qtris, room for n_wnodes and
 // n_tri records of 64 bytes).  *bad becomes non-zero if some box does not quantise (a bound
@@ -226,8 +227,8 @@ unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &
 inline unsigned int persistent_lds_bytes(const PersistentParams &pp) {
     return (unsigned int)((pp.stack_cap + 1) * PT_TRACE_BLOCK * 4 + 64 * pp.cache_nodes);
 }
-// The loop parameters of a launch on scene s: the cache applies to single-level scenes only and
-// never holds more nodes than the scene has prepared.
+// The loop parameters of a launch on scene s: the cache never holds more nodes than the scene
+// has prepared (of a two-level scene: nodes of the top-level tree).
 inline PersistentParams persistent_params(const ExtendConfig &cfg, const DeviceScene &s) {
     PersistentParams pp;
     pp.refill = cfg.refill;
@@ -236,7 +237,7 @@ inline PersistentParams persistent_params(const ExtendConfig &cfg, const DeviceS
     pp.spill_entries = cfg.spill_entries;
     pp.stack_cap = cfg.stack_entries;
     const int top_nodes = (int)(cfg.quad ? s.n_q_top_cache : s.n_top_cache);
-    pp.cache_nodes = s.tlas ? 0 : (cfg.cache_nodes < top_nodes ? cfg.cache_nodes : top_nodes);
+    pp.cache_nodes = cfg.cache_nodes < top_nodes ? cfg.cache_nodes : top_nodes;
     if (pp.cache_nodes < 0) pp.cache_nodes = 0;
     pp.xcd_slots = cfg.xcd_slots;
     return pp;

@@ -1005,6 +1005,38 @@ struct HitSink {
     }
 };
 
+// The workgroup's copy of the top of the tree (DeviceScene::top_cache, or q_top_cache for the
+// four-child nodes; for a two-level scene the top of the top-level tree): the first
+// pp.cache_nodes nodes go to LDS, and the children beyond the workgroup's share get their global
+// names back.  All threads of the workgroup call it; true if anything was copied.
+template <bool QUAD>
+__device__ __forceinline__ bool copy_top_to_lds(const DeviceScene &s, const PersistentParams &pp,
+                                                LdsFloat4 *cache) {
+    const float4 *const top = QUAD ? s.q_top_cache : s.top_cache;
+    const int32_t *const top_global = QUAD ? s.q_top_global : s.top_global;
+    const uint32_t n_cached = min((uint32_t)pp.cache_nodes, QUAD ? s.n_q_top_cache : s.n_top_cache);
+    for (uint32_t i = threadIdx.x; i < 4u * n_cached; i += kTraceBlock) {
+        float4 v = top[i];
+        if ((i & 3u) == 3u) {
+            int32_t c0 = __float_as_int(v.x), c1 = __float_as_int(v.y);
+            if (c0 >= kLdsNodeBase + (int32_t)n_cached) c0 = top_global[c0 - kLdsNodeBase];
+            if (c1 >= kLdsNodeBase + (int32_t)n_cached) c1 = top_global[c1 - kLdsNodeBase];
+            v.x = __int_as_float(c0);
+            v.y = __int_as_float(c1);
+            if constexpr (QUAD) {
+                int32_t c2 = __float_as_int(v.z), c3 = __float_as_int(v.w);
+                if (c2 >= kLdsNodeBase + (int32_t)n_cached) c2 = top_global[c2 - kLdsNodeBase];
+                if (c3 >= kLdsNodeBase + (int32_t)n_cached) c3 = top_global[c3 - kLdsNodeBase];
+                v.z = __int_as_float(c2);
+                v.w = __int_as_float(c3);
+            }
+        }
+        lds_store4(cache + i, v);
+    }
+    __syncthreads();
+    return n_cached != 0;
+}
+
 // Rays[0..n) by persistent waves: the grid is sized to the machine, not to the queue.
 // Chunks of 64 rays are dealt round-robin to the waves (chunk c belongs to wave c % n_waves:
 // static, so no work-distribution atomics), and a wave tops its idle lanes up from its own
@@ -1027,31 +1059,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     // fewer nodes than the array holds gives the children beyond its share their global names.
     LdsFloat4 *const cache = CACHE ? persistent_cache(stack_cap) : nullptr;
     int32_t root = 0;
-    if (CACHE) {
-        const float4 *const top = QUAD ? s.q_top_cache : s.top_cache;
-        const int32_t *const top_global = QUAD ? s.q_top_global : s.top_global;
-        const uint32_t n_cached = min((uint32_t)pp.cache_nodes, QUAD ? s.n_q_top_cache : s.n_top_cache);
-        for (uint32_t i = threadIdx.x; i < 4u * n_cached; i += kTraceBlock) {
-            float4 v = top[i];
-            if ((i & 3u) == 3u) {
-                int32_t c0 = __float_as_int(v.x), c1 = __float_as_int(v.y);
-                if (c0 >= kLdsNodeBase + (int32_t)n_cached) c0 = top_global[c0 - kLdsNodeBase];
-                if (c1 >= kLdsNodeBase + (int32_t)n_cached) c1 = top_global[c1 - kLdsNodeBase];
-                v.x = __int_as_float(c0);
-                v.y = __int_as_float(c1);
-                if constexpr (QUAD) {
-                    int32_t c2 = __float_as_int(v.z), c3 = __float_as_int(v.w);
-                    if (c2 >= kLdsNodeBase + (int32_t)n_cached) c2 = top_global[c2 - kLdsNodeBase];
-                    if (c3 >= kLdsNodeBase + (int32_t)n_cached) c3 = top_global[c3 - kLdsNodeBase];
-                    v.z = __int_as_float(c2);
-                    v.w = __int_as_float(c3);
-                }
-            }
-            lds_store4(cache + i, v);
-        }
-        __syncthreads();
-        if (n_cached) root = kLdsNodeBase;
-    }
+    if (CACHE && copy_top_to_lds<QUAD>(s, pp, cache)) root = kLdsNodeBase;
     const uint32_t lane = threadIdx.x & 63u;
     // readfirstlane: the wave index is the same in all 64 lanes, which the compiler cannot see
     // from threadIdx; with it the stream bookkeeping and the loop control stay scalar
@@ -1295,13 +1303,17 @@ __device__ __forceinline__ bool ray_is_ordinary(const float4 ro, const float4 rd
     return (fabsf(chk) < INFINITY) && (ro.w == ro.w) && !(rd.x == 0.f && rd.y == 0.f && rd.z == 0.f);
 }
 
-template <bool COUNT, bool ANY, bool BIG, class Sink>
+template <bool COUNT, bool ANY, bool BIG, class Sink, bool CACHE = false>
 __device__ __forceinline__ void persistent_traverse_two_level(
     const DeviceScene &s, const pt_ray *rays, uint32_t n, bool fixup, const PersistentParams pp,
     unsigned int *tie_count, DeviceTraceCounters *work, Sink sink) {
     const int refill = pp.refill, leaf_lanes = pp.leaf_lanes, stack_cap = pp.stack_cap;
     int32_t *const stack = persistent_stack();
     const StackSpill spill = lane_spill(pp.spill, pp.spill_entries);
+    // the top of the top-level tree, which every ray walks first, from LDS (as one level down)
+    LdsFloat4 *const cache = CACHE ? persistent_cache(stack_cap) : nullptr;
+    int32_t top_root = (int32_t)s.top_root;
+    if (CACHE && copy_top_to_lds<false>(s, pp, cache)) top_root = kLdsNodeBase;
     const uint32_t lane = threadIdx.x & 63u;
     // readfirstlane: the wave index is the same in all 64 lanes, which the compiler cannot see
     // from threadIdx; with it the stream bookkeeping and the loop control stay scalar
@@ -1376,7 +1388,7 @@ __device__ __forceinline__ void persistent_traverse_two_level(
                     spilled = 0;
                     stack[0] = kSentinel;
                     st.sp = 1;
-                    st.cur = (int32_t)s.top_root;               // the top-level root
+                    st.cur = top_root;                          // the top-level root
                     st.tie = !ray_is_ordinary(ro, rd);          // whatever the fixed order makes of it
                     if (st.tie) st.cur = kSentinel;
                 }
@@ -1409,9 +1421,17 @@ __device__ __forceinline__ void persistent_traverse_two_level(
             // node steps in a loop of their own: only position and stack pointer change in it
             while (mode == 0) {
                 if (at_node) {
-                    const float4 *np = wide_node<BIG>(s, st.cur);
-                    const float4 a = np[0], b = np[1], c = np[2];
-                    const int2 ch = reinterpret_cast<const int2 *>(np + 3)[0];
+                    float4 a, b, c;
+                    int2 ch;
+                    if (CACHE && st.cur >= kLdsNodeBase) {      // a node of the top of the top level, in LDS
+                        const LdsFloat4 *np = cache + ((st.cur - kLdsNodeBase) << 2);
+                        a = lds_load4(np); b = lds_load4(np + 1); c = lds_load4(np + 2);
+                        ch = lds_load_int2(np + 3);
+                    } else {
+                        const float4 *np = wide_node<BIG>(s, st.cur);
+                        a = np[0]; b = np[1]; c = np[2];
+                        ch = reinterpret_cast<const int2 *>(np + 3)[0];
+                    }
                     if (COUNT) nb += 2;
                     float ta, tb;
                     const bool ha = intersect_box(st.r, a.x, a.y, a.z, a.w, c.x, c.y, st.bound, ta);

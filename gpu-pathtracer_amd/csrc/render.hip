@@ -124,11 +124,12 @@ __global__ __launch_bounds__(kBlock) void k_pt_extend_two_level(DeviceScene s, c
     }
 }
 
-template <bool COUNT, bool BIG>
+template <bool COUNT, bool BIG, bool CACHE>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_two_level_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, const unsigned int *count,
     unsigned int *tie_count, DeviceTraceCounters *work, PersistentParams pp) {
-    persistent_traverse_two_level<COUNT, false, BIG>(s, rays, *count, true, pp, tie_count, work, HitSink{hits});
+    persistent_traverse_two_level<COUNT, false, BIG, HitSink, CACHE>(s, rays, *count, true, pp, tie_count, work,
+                                                                    HitSink{hits});
 }
 
 // extend, persistent form: the grid is sized to the machine, not to the queue.  Queue
@@ -274,11 +275,11 @@ __global__ __launch_bounds__(kBlock) void k_pt_occlude_two_level(DeviceScene s, 
     ShadowSink{ws.shadow_carry, ws.radiance}((uint32_t)i, occ);
 }
 
-template <bool BIG>
+template <bool BIG, bool CACHE>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_two_level_persistent(
     DeviceScene s, RenderWorkspace ws, const unsigned int *count, PersistentParams pp) {
-    persistent_traverse_two_level<false, true, BIG>(s, ws.shadow_rays, *count, true, pp, nullptr, nullptr,
-                                               ShadowSink{ws.shadow_carry, ws.radiance});
+    persistent_traverse_two_level<false, true, BIG, ShadowSink, CACHE>(s, ws.shadow_rays, *count, true, pp, nullptr,
+                                                                      nullptr, ShadowSink{ws.shadow_carry, ws.radiance});
 }
 
 // Persistent waves with lane refill and step voting, as the closest-hit kernel.
@@ -355,9 +356,16 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
     if (!max_rays) return;
     const PersistentParams pp = persistent_params(cfg, s);
     if (s.tlas && cfg.persistent_blocks > 0) {
-        auto k = work ? (s.big ? k_pt_extend_two_level_persistent<true, true> : k_pt_extend_two_level_persistent<true, false>)
-                      : (s.big ? k_pt_extend_two_level_persistent<false, true> : k_pt_extend_two_level_persistent<false, false>);
-        launch_persistent(k, st, blocks(max_rays, kBlock), cfg, pp, s, (const pt_ray *)ws.rays[buf], ws.hits, count,
+        using K = void (*)(DeviceScene, const pt_ray *, pt_hit *, const unsigned int *, unsigned int *,
+                           DeviceTraceCounters *, PersistentParams);
+        // template arguments: counting, 64-bit record addresses, cached top of the top-level tree
+        static const K table[8] = {
+            k_pt_extend_two_level_persistent<false, false, false>, k_pt_extend_two_level_persistent<false, false, true>,
+            k_pt_extend_two_level_persistent<false, true, false>,  k_pt_extend_two_level_persistent<false, true, true>,
+            k_pt_extend_two_level_persistent<true, false, false>,  k_pt_extend_two_level_persistent<true, false, true>,
+            k_pt_extend_two_level_persistent<true, true, false>,   k_pt_extend_two_level_persistent<true, true, true>};
+        launch_persistent(table[(work ? 4 : 0) | (s.big ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)], st,
+                          blocks(max_rays, kBlock), cfg, pp, s, (const pt_ray *)ws.rays[buf], ws.hits, count,
                           tie_count, work, pp);
         return;
     }
@@ -414,8 +422,12 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
     if (!max_rays) return;
     const PersistentParams pp = persistent_params(cfg, s);
     if (s.tlas && cfg.persistent_blocks > 0) {
-        launch_persistent(s.big ? k_pt_occlude_two_level_persistent<true> : k_pt_occlude_two_level_persistent<false>,
-                          st, blocks(max_rays, kBlock), cfg, pp, s, ws, shadow_count, pp);
+        using K = void (*)(DeviceScene, RenderWorkspace, const unsigned int *, PersistentParams);
+        static const K table[4] = {
+            k_pt_occlude_two_level_persistent<false, false>, k_pt_occlude_two_level_persistent<false, true>,
+            k_pt_occlude_two_level_persistent<true, false>,  k_pt_occlude_two_level_persistent<true, true>};
+        launch_persistent(table[(s.big ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)], st, blocks(max_rays, kBlock), cfg, pp,
+                          s, ws, shadow_count, pp);
         return;
     }
     if (s.tlas) {

@@ -149,18 +149,18 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_two_level(DeviceScene s, c
 }
 
 // Two-level scenes by persistent waves (see persistent_traverse_two_level).
-template <bool COUNT, bool BIG>
+template <bool COUNT, bool BIG, bool CACHE>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_two_level_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, uint32_t n, bool fixup, PersistentParams pp,
     DeviceTraceCounters *counters) {
-    persistent_traverse_two_level<COUNT, false, BIG>(s, rays, n, fixup, pp, &counters->tie_count, counters,
-                                                HitSink{hits});
+    persistent_traverse_two_level<COUNT, false, BIG, HitSink, CACHE>(s, rays, n, fixup, pp, &counters->tie_count,
+                                                                    counters, HitSink{hits});
 }
-template <bool BIG>
+template <bool BIG, bool CACHE>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_two_level_persistent(
     DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, PersistentParams pp) {
-    persistent_traverse_two_level<false, true, BIG>(s, rays, n, true, pp, nullptr, nullptr,
-                                               OccludedSink{occluded});
+    persistent_traverse_two_level<false, true, BIG, OccludedSink, CACHE>(s, rays, n, true, pp, nullptr, nullptr,
+                                                                        OccludedSink{occluded});
 }
 
 // Sort key of a ray: 30-bit Morton code of its origin's cell in a 1024^3 grid over the scene's
@@ -220,11 +220,11 @@ __global__ __launch_bounds__(kBlock) void k_ray_keys(DeviceScene s, const pt_ray
 // position.  The queue is kept: it names each cache node's place in wnodes.  One thread: a few
 // hundred dependent fetches, once per scene.
 __global__ void k_build_top_cache(const float4 *wnodes, uint32_t n_wnodes, float4 *cache,
-                                  int32_t *queue, uint32_t *n_out, int capacity) {
+                                  int32_t *queue, uint32_t *n_out, int capacity, uint32_t root) {
     if (blockIdx.x || threadIdx.x) return;
     int count = 0;
     if (n_wnodes > 1 && capacity > 0) {
-        queue[0] = 0;
+        queue[0] = (int32_t)root;
         count = 1;
         for (int i = 0; i < count; ++i) {
             const float4 *np = wnodes + 4 * (size_t)queue[i];
@@ -378,9 +378,9 @@ void launch_build_quad_top_cache(hipStream_t st, const float4 *qnodes, uint32_t 
 }
 
 void launch_build_top_cache(hipStream_t st, const float4 *wnodes, uint32_t n_wnodes, float4 *cache,
-                            int32_t *global_index, uint32_t *n_out) {
+                            int32_t *global_index, uint32_t *n_out, uint32_t root) {
     hipLaunchKernelGGL(k_build_top_cache, dim3(1), dim3(1), 0, st, wnodes, n_wnodes, cache,
-                       global_index, n_out, (int)kNodeCacheMax);
+                       global_index, n_out, (int)kNodeCacheMax, root);
 }
 
 namespace {
@@ -513,9 +513,15 @@ void launch_trace_two_level(hipStream_t st, const DeviceScene &s, const pt_ray *
     if (n == 0) return;
     if (!exact && cfg.persistent_blocks > 0) {
         const PersistentParams pp = persistent_params(cfg, s);
-        auto k = count_work ? (s.big ? k_trace_two_level_persistent<true, true> : k_trace_two_level_persistent<true, false>)
-                            : (s.big ? k_trace_two_level_persistent<false, true> : k_trace_two_level_persistent<false, false>);
-        launch_persistent(k, st, grid_for(n), cfg, pp, s, rays, hits, (uint32_t)n, fixup, pp, counters);
+        using K = void (*)(DeviceScene, const pt_ray *, pt_hit *, uint32_t, bool, PersistentParams, DeviceTraceCounters *);
+        // template arguments: counting, 64-bit record addresses, cached top of the top-level tree
+        static const K table[8] = {
+            k_trace_two_level_persistent<false, false, false>, k_trace_two_level_persistent<false, false, true>,
+            k_trace_two_level_persistent<false, true, false>,  k_trace_two_level_persistent<false, true, true>,
+            k_trace_two_level_persistent<true, false, false>,  k_trace_two_level_persistent<true, false, true>,
+            k_trace_two_level_persistent<true, true, false>,   k_trace_two_level_persistent<true, true, true>};
+        launch_persistent(table[(count_work ? 4 : 0) | (s.big ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)], st, grid_for(n),
+                          cfg, pp, s, rays, hits, (uint32_t)n, fixup, pp, counters);
         return;
     }
     if (count_work)
@@ -600,8 +606,12 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
     if (s.tlas) {
         if (!exact_order && cfg.persistent_blocks > 0) {
             const PersistentParams pp = persistent_params(cfg, s);
-            launch_persistent(s.big ? k_trace_any_two_level_persistent<true> : k_trace_any_two_level_persistent<false>,
-                              st, grid_for(n), cfg, pp, s, rays, occluded, (uint32_t)n, pp);
+            using K = void (*)(DeviceScene, const pt_ray *, int32_t *, uint32_t, PersistentParams);
+            static const K table[4] = {
+                k_trace_any_two_level_persistent<false, false>, k_trace_any_two_level_persistent<false, true>,
+                k_trace_any_two_level_persistent<true, false>,  k_trace_any_two_level_persistent<true, true>};
+            launch_persistent(table[(s.big ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)], st, grid_for(n), cfg, pp, s, rays,
+                              occluded, (uint32_t)n, pp);
             return;
         }
         hipLaunchKernelGGL(k_trace_any_two_level, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays,

@@ -50,6 +50,16 @@ def test_closest_and_any_hits_are_bit_exact(mipt, oracle, gpu_ctx, builder):
             np.testing.assert_array_equal(scene.trace_any(rays), t.any_hit(rays, nthreads=8))
         finally:
             gpu_ctx.set_option("any.exact_order", 0)
+        # the top of the top-level tree cached in LDS (off by default on two-level scenes), with few
+        # stack entries left per lane: same answers
+        gpu_ctx.set_option("extend.cache_nodes", 160)
+        gpu_ctx.set_option("extend.stack_entries", 12)
+        try:
+            assert same_hits(scene.trace_closest(rays), want, nan_equal=True).size == 0
+            np.testing.assert_array_equal(scene.trace_any(rays), t.any_hit(rays, nthreads=8))
+        finally:
+            gpu_ctx.set_option("extend.cache_nodes", -1)
+            gpu_ctx.set_option("extend.stack_entries", -1)
         # one thread per ray instead of persistent waves: same answers
         gpu_ctx.set_option("extend.persistent", 0)
         try:
