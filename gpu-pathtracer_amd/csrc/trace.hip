@@ -218,7 +218,10 @@ __global__ __launch_bounds__(kBlock) void k_ray_keys(DeviceScene s, const pt_ray
 // Breadth-first from the root: the node taken from the queue at position i becomes cache node i,
 // and a child that is itself queued (while there is room) is renamed kLdsNodeBase + its queue
 // position.  The queue is kept: it names each cache node's place in wnodes.  One thread: a few
-// hundred dependent fetches, once per scene.
+// hundred dependent fetches, once per scene.  (Taking the pending node with the largest box
+// first instead -- the nodes a ray is most likely to meet -- was measured on the benchmark
+// scene: 31.5 instead of 31.7 of a ray's 67.4 slab tests served from LDS, launch time within
+// 0.5 %: breadth first already holds the nodes that matter.)
 __global__ void k_build_top_cache(const float4 *wnodes, uint32_t n_wnodes, float4 *cache,
                                   int32_t *queue, uint32_t *n_out, int capacity, uint32_t root) {
     if (blockIdx.x || threadIdx.x) return;
