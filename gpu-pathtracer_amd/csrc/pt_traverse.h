@@ -36,6 +36,12 @@ namespace mipt {
 #ifndef PT_EXTEND_MIN_WAVES
 #define PT_EXTEND_MIN_WAVES 1
 #endif
+// The closest-hit loop over both levels of a two-level scene needs 106 registers left to itself,
+// i.e. four waves per SIMD; held to five (96 registers, six spilled outside the loops) it traces
+// 4096 placements of a 65 K-triangle mesh at 3.08 instead of 2.85 Grays/s.
+#ifndef PT_TWO_LEVEL_MIN_WAVES
+#define PT_TWO_LEVEL_MIN_WAVES 5
+#endif
 
 constexpr int kTraceBlock = PT_TRACE_BLOCK;
 constexpr int kTraceStack = PT_LDS_STACK_ENTRIES;
@@ -413,7 +419,45 @@ struct OrderedState {
     // the tie flag came from a value that is not finite (the ray, or a hit distance): what the
     // fixed order makes of such a ray is not bounded by any hit found here
     bool wild;
+    // Four-child walk only (see coarse_ray_terms): per axis, 1/d made safe for the coarse slab
+    // test (0 where the direction component is zero or next to it) and the allowance by which
+    // that test widens each slab (infinite on such an axis).
+    float qax, qay, qaz, qmx, qmy, qmz;
 };
+
+// The coarse boxes of a four-child node need no more than to contain the exact ones, so their
+// slab test need not be the reference's expression: distance of a decoded plane
+//   fl(fl(fl(q * scale + org) - o) * inv)          three instructions per plane, as in the shader
+// becomes
+//   fl(q * A + B),  A = fl(scale * inv),  B = fl(fl(org - o) * inv) -/+ m
+// one instruction per plane and fifteen per node.  The two differ by rounding, by less than
+// 9 u |inv| (C + |o|) with u = 2^-24 and C the largest coordinate of the scene (each of the
+// eight roundings involved acts on a term bounded by the node's extent, the plane's coordinate or
+// its distance from the origin), so with m = 2^-20 |inv| (C + |o|) the near planes come out no
+// later and the far planes no earlier than in the reference's form: a ray that passes the
+// reference's test on a child's exact box passes this one.  Relative to a slab's width m is
+// about 1e-6 C / (box size): nothing is let in that matters.  An axis along which the ray does
+// not move (1 / d infinite, or too large for the products to stay finite) gets A = 0 and
+// B = -/+ infinity: no constraint from that axis, which is again only wider.
+__device__ __forceinline__ void coarse_ray_terms(OrderedState &st, float cmax) {
+    const float kAllow = 9.5367431640625e-07f;      // 2^-20
+    const float ax = fabsf(st.r.ix), ay = fabsf(st.r.iy), az = fabsf(st.r.iz);
+    const bool okx = ax < 1.0e30f, oky = ay < 1.0e30f, okz = az < 1.0e30f;
+    st.qax = okx ? st.r.ix : 0.f;
+    st.qay = oky ? st.r.iy : 0.f;
+    st.qaz = okz ? st.r.iz : 0.f;
+    st.qmx = okx ? kAllow * (ax * (cmax + fabsf(st.r.ox))) : INFINITY;
+    st.qmy = oky ? kAllow * (ay * (cmax + fabsf(st.r.oy))) : INFINITY;
+    st.qmz = okz ? kAllow * (az * (cmax + fabsf(st.r.oz))) : INFINITY;
+}
+// Largest coordinate of the scene, a little generous (the decoded boxes may stick out of the
+// root box by a rounding step).
+__device__ __forceinline__ float scene_max_coordinate(const DeviceScene &s) {
+    const float4 lo = s.nodes[0], hi = s.nodes[1];
+    const float c = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))),
+                          fmaxf(fabsf(lo.z), fabsf(hi.z)));
+    return c * 1.001f;
+}
 
 __device__ __forceinline__ void ordered_begin(OrderedState &st, const float4 ro, const float4 rd,
                                               int32_t *stack, int32_t root = 0, int base = 0) {
@@ -543,6 +587,28 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                 const uint32_t qnx = sgx ? qhx : qlx, qfx = sgx ? qlx : qhx;
                 const uint32_t qny = sgy ? qhy : qly, qfy = sgy ? qly : qhy;
                 const uint32_t qnz = sgz ? qhz : qlz, qfz = sgz ? qlz : qhz;
+#ifndef PT_QUAD_REFERENCE_FORM
+                // see coarse_ray_terms
+                const float cax = f0.w * st.qax, cay = f1.x * st.qay, caz = f1.y * st.qaz;
+                const float cbx = (f0.x - st.r.ox) * st.qax, cby = (f0.y - st.r.oy) * st.qay,
+                            cbz = (f0.z - st.r.oz) * st.qaz;
+                const float bnx = cbx - st.qmx, bny = cby - st.qmy, bnz = cbz - st.qmz;
+                const float bfx = cbx + st.qmx, bfy = cby + st.qmy, bfz = cbz + st.qmz;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float nx = __builtin_fmaf((float)((qnx >> (8 * k)) & 0xffu), cax, bnx);
+                    const float ny = __builtin_fmaf((float)((qny >> (8 * k)) & 0xffu), cay, bny);
+                    const float nz = __builtin_fmaf((float)((qnz >> (8 * k)) & 0xffu), caz, bnz);
+                    const float fx = __builtin_fmaf((float)((qfx >> (8 * k)) & 0xffu), cax, bfx);
+                    const float fy = __builtin_fmaf((float)((qfy >> (8 * k)) & 0xffu), cay, bfy);
+                    const float fz = __builtin_fmaf((float)((qfz >> (8 * k)) & 0xffu), caz, bfz);
+                    const float t1 = fminf(fminf(fx, fminf(fy, fz)), st.bound);
+                    const float t0 = fmaxf(fmaxf(nx, fmaxf(ny, nz)), 0.0f);
+                    const bool h = (t1 >= t0) && ref[k] != kNoChild;
+                    key[k] = h ? fminf(t0, 3.0e38f) : INFINITY;
+                    nh += h ? 1 : 0;
+                }
+#else
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float pnx = __builtin_fmaf((float)((qnx >> (8 * k)) & 0xffu), f0.w, f0.x);
@@ -560,6 +626,18 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                     key[k] = h ? fminf(t0, 3.0e38f) : INFINITY;
                     nh += h ? 1 : 0;
                 }
+#endif
+#ifdef PT_EXP_QUAD_EXTRA
+                // experiment: PT_EXP_QUAD_EXTRA more vector instructions per four-child step (what
+                // the launch pays -- or would save -- per instruction of this step)
+                {
+                    float acc = key[0];
+#pragma unroll
+                    for (int e = 0; e < PT_EXP_QUAD_EXTRA; ++e)
+                        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(f0.x), "v"(f0.y));
+                    if (acc == 12345.678f) key[0] = acc;
+                }
+#endif
                 // children in order of entry distance (misses last): five compare-exchanges
 #define PT_CE(a, b)                                                        \
     {                                                                      \
@@ -597,14 +675,25 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                     const LdsFloat4 *np = cache + ((st.cur - kLdsNodeBase) << 2);
                     a = lds_load4(np); b = lds_load4(np + 1); c = lds_load4(np + 2);
                     ch = lds_load_int2(np + 3);
+#ifndef PT_WAVE_ITERS
                     if (COUNT && nl) *nl += 2;
+#endif
                 } else {
                     const float4 *np = wide_node<BIG>(s, st.cur);
                     a = np[0]; b = np[1]; c = np[2];
                     ch = reinterpret_cast<const int2 *>(np + 3)[0];
                 }
 #ifdef PT_WAVE_ITERS
+                // instrumented build: node steps per wave (x128, in place of the slab tests), and of
+                // those the steps in which every lane of the step stands at one and the same node
+                // of the LDS copy (x128, in place of the slab tests on LDS nodes)
                 if (COUNT && (__ffsll(__ballot(1)) - 1) == (int)(threadIdx.x & 63)) nb += 128;
+                {
+                    const int32_t first_node = __builtin_amdgcn_readfirstlane(st.cur);
+                    const bool uniform = __ballot(st.cur == first_node) == __ballot(1) &&
+                                         first_node >= kLdsNodeBase;
+                    if (COUNT && nl && uniform && (__ffsll(__ballot(1)) - 1) == (int)(threadIdx.x & 63)) *nl += 128;
+                }
 #else
                 if (COUNT) nb += 2;
 #endif
@@ -666,9 +755,22 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                 continue;
             }
             float h0 = 0.f, h1 = 0.f, h2 = 0.f, ht = 0.f;
-            const bool hit = intersect_triangle_watertight(st.r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y,
-                                                           q1.z, q1.w, q2.x, st.bound, h0, h1, h2, ht) &
-                             in_leaf_box;
+#ifdef PT_EXP_TRI_TWICE
+            // experiment: the triangle test a second time on inputs the compiler cannot tell are
+            // the same -- what the launch pays per triangle step's worth of vector instructions
+            float zero;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+            float g0, g1, g2, gt;
+            const bool hit_again = intersect_triangle_watertight(st.r, q0.x + zero, q0.y, q0.z, q0.w, q1.x, q1.y,
+                                                                 q1.z, q1.w, q2.x, st.bound, g0, g1, g2, gt);
+#endif
+            bool hit = intersect_triangle_watertight(st.r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y,
+                                                     q1.z, q1.w, q2.x, st.bound, h0, h1, h2, ht) &
+                       in_leaf_box;
+#ifdef PT_EXP_TRI_TWICE
+            hit &= (hit_again == hit) | !in_leaf_box | true;
+            if (hit_again && !(gt == ht)) ht = gt;          // never taken for finite distances
+#endif
             const bool bad = hit & !(ht == ht);
             const bool had = st.primid >= 0;
             const bool closer = hit & !bad & (!had | (ht < st.tbest));
@@ -1060,6 +1162,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     LdsFloat4 *const cache = CACHE ? persistent_cache(stack_cap) : nullptr;
     int32_t root = 0;
     if (CACHE && copy_top_to_lds<QUAD>(s, pp, cache)) root = kLdsNodeBase;
+    const float cmax = QUAD ? scene_max_coordinate(s) : 0.f;
     const uint32_t lane = threadIdx.x & 63u;
     // readfirstlane: the wave index is the same in all 64 lanes, which the compiler cannot see
     // from threadIdx; with it the stream bookkeeping and the loop control stay scalar
@@ -1214,6 +1317,7 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                     const float4 rd = reinterpret_cast<const float4 *>(rays + ri)[1];
                     if constexpr (ANY) any_begin(st, ro, rd, stack, any_exact, root);
                     else ordered_begin(st, ro, rd, stack, root);
+                    if constexpr (QUAD) coarse_ray_terms(st, cmax);
                     my_ray = ri;
                     spilled = 0;
                 }

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void k_pt_extend_two_level(DeviceScene s, c
 }
 
 template <bool COUNT, bool BIG, bool CACHE>
-__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_extend_two_level_persistent(
+__global__ __launch_bounds__(kBlock, PT_TWO_LEVEL_MIN_WAVES) void k_pt_extend_two_level_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, const unsigned int *count,
     unsigned int *tie_count, DeviceTraceCounters *work, PersistentParams pp) {
     persistent_traverse_two_level<COUNT, false, BIG, HitSink, CACHE>(s, rays, *count, true, pp, tie_count, work,

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_two_level(DeviceScene s, c
 
 // Two-level scenes by persistent waves (see persistent_traverse_two_level).
 template <bool COUNT, bool BIG, bool CACHE>
-__global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_two_level_persistent(
+__global__ __launch_bounds__(kBlock, PT_TWO_LEVEL_MIN_WAVES) void k_trace_two_level_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, uint32_t n, bool fixup, PersistentParams pp,
     DeviceTraceCounters *counters) {
     persistent_traverse_two_level<COUNT, false, BIG, HitSink, CACHE>(s, rays, n, fixup, pp, &counters->tie_count,

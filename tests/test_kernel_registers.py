@@ -1,9 +1,11 @@
-"""The persistent traversal kernels are launched five workgroups of four waves per compute unit,
-i.e. five waves per SIMD, which the 512 vector registers of a SIMD lane allow only up to 96
-registers per lane (allocated in eights).  A change that takes the hot kernels past that --
-typically in a rarely taken path inlined into them -- costs a tenth of the benchmark without
-failing anything, so the register counts of the built code objects are checked here (CPU only:
-reads the device code embedded in the object files of the in-tree build)."""
+"""The persistent traversal kernels over two-child nodes are launched five workgroups of four
+waves per compute unit, i.e. five waves per SIMD, which the 512 vector registers of a SIMD lane
+allow only up to 96 registers per lane (allocated in eights).  A change that takes the hot kernels
+past that -- typically in a rarely taken path inlined into them -- costs a tenth of the benchmark
+without failing anything, so the register counts of the built code objects are checked here (CPU
+only: reads the device code embedded in the object files of the in-tree build).  The kernels over
+four-child nodes, which run on scenes beyond the caches, are faster with four waves per SIMD and
+may take up to 104."""
 import os
 import re
 import shutil
@@ -42,5 +44,7 @@ def test_hot_kernels_keep_five_waves_per_simd(tmp_path, obj, kernel):
     meta = {k: v for k, v in _kernel_metadata(path, tmp_path).items() if kernel in k and "two_level" not in k}
     assert meta, f"no kernel matching {kernel} in {obj}"
     for name, m in meta.items():
-        assert m["vgpr_count"] <= 96, (name, m)
+        # the last template argument of the closest-hit kernels says four-child nodes
+        quad = name.split("EEEv")[0].endswith("ELb1") and ("extend" in name or "ordered" in name)
+        assert m["vgpr_count"] <= (104 if quad else 96), (name, m)
         assert m["vgpr_spill_count"] == 0 and m["sgpr_spill_count"] == 0, (name, m)
