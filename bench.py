@@ -432,7 +432,7 @@ def main():
             out["roofline"]["hbm_frac_from_traffic"] = gb / (extend_ms / max(launches, 1) * 1e-3) / HBM_PEAK_GBS
         elif live.get("error"):
             out["roofline"]["live_counters_failed"] = live["error"]
-        tpath = os.path.join(REPO, "profiles", "r02_traffic.json")
+        tpath = os.path.join(REPO, "profiles", "r03_traffic.json")
         if os.path.exists(tpath) and world == 1:
             with open(tpath) as f:
                 tr = json.load(f)
@@ -441,7 +441,7 @@ def main():
             if same and out["roofline"]["traffic"] is None:
                 gb = tr["traffic_bytes_per_launch"] / 1e9
                 out["roofline"]["traffic"] = gb
-                out["roofline"]["traffic_source"] = ("GB per launch, copied from profiles/r02_traffic.json (rocprofv3 "
+                out["roofline"]["traffic_source"] = ("GB per launch, copied from profiles/r03_traffic.json (rocprofv3 "
                                                      "--pmc passes over this command; FETCH_SIZE calibrated there "
                                                      "on 64-byte gathers of known size), not measured by this run")
                 out["roofline"]["hbm_frac_from_traffic"] = gb / (extend_ms / max(launches, 1) * 1e-3) / HBM_PEAK_GBS

@@ -638,7 +638,10 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                     if (acc == 12345.678f) key[0] = acc;
                 }
 #endif
-                // children in order of entry distance (misses last): five compare-exchanges
+                // children in order of entry distance (misses last): five compare-exchanges.  (Singling
+                // out only the nearest child and pushing the others in child order saves a fifth of
+                // the step's instructions and was measured 3-5 % slower on the 28 M-triangle scenes:
+                // the order in which the pushed siblings are taken up matters.)
 #define PT_CE(a, b)                                                        \
     {                                                                      \
         const bool sw = key[b] < key[a];                                   \

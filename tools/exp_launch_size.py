@@ -17,13 +17,23 @@ for a in sys.argv[1:]:
 gen = scenes.displaced_cube_sphere if os.environ.get("SCENE", "uv") == "cube" else scenes.displaced_sphere
 vtx, idx, _, _ = gen(int(os.environ.get("TRIS", "28000000")), seed=7)
 ctx.set_option("build.optimize_passes", int(os.environ.get("PASSES", "8")))
+import time
+ctx.synchronize()
+_t0 = time.perf_counter()
 sc = mipt.Scene(ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
+ctx.synchronize()
+build_s = time.perf_counter() - _t0
 nmax = 1 << 25
 FLAGS = int(os.environ.get("FLAGS", "0"))       # 4: PT_TRACE_NO_TIE_FIXUP
 rays = scenes.surface_rays(vtx, idx, nmax, seed=7)
 d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
 d_h = torch.empty_like(d_r)
+ctx.set_option("extend.quad", 0)
+_st = sc.trace_closest_device_counted(d_r.data_ptr(), 1 << 22, d_h.data_ptr())
+ctx.set_option("extend.quad", -1)
 print(json.dumps({"scene": os.environ.get("SCENE", "uv"), "tris": int(idx.shape[0]), "depth": sc.tree_depth(),
+                  "build_s": round(build_s, 3), "boxes_per_ray": round(_st.box_tests / (1 << 22), 2),
+                  "tris_per_ray": round(_st.tri_tests / (1 << 22), 2),
                   "leaves": (int(mipt.lib.pt_scene_node_count(sc._h)) + 1) // 2}), flush=True)
 for lg in [int(x) for x in os.environ.get('LGS', '20 21 22 23 24 25').split()]:
     n = 1 << lg
