@@ -574,7 +574,7 @@ def hbm_record(args, ctx, torch, mipt, scenes, kind=None, live=None):
     n = args.hbm_rays
     rays = scenes.surface_rays(vtx, idx, n, seed=7)
     gen_s = time.time() - t0
-    ctx.set_option("build.optimize_passes", 8)
+    ctx.set_option("build.optimize_passes", 6)      # with the default treelet round after every third
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sc = mipt.Scene(ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
@@ -627,7 +627,7 @@ def hbm_record(args, ctx, torch, mipt, scenes, kind=None, live=None):
                      "are those of the two-child walk of the same tree on the same rays",
            "workload": "Lucy-class displaced closed surface (%s), %d tris in %d leaves (%.2f GB of 64-byte node "
                        "and triangle records), %d secondary rays (origins on the surface, cosine directions, "
-                       "seed 7), tree built on the GPU with 8 optimisation passes in %.2f s" %
+                       "seed 7), tree built on the GPU with 6 insertion and 2 treelet passes in %.2f s" %
                        ("latitude / longitude tessellation: two pole fans of thousands of sliver triangles, each "
                         "sliver cut into several leaves" if kind == "uv"
                         else "cube faces pushed out to the sphere: triangles of nearly uniform size",

@@ -438,6 +438,9 @@ int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
     } else if (k == "build.optimize_passes") {
         if (v < 0 || v > 32) return fail(PT_ERR_INVALID, "build.optimize_passes must be in [0,32]");
         ctx->build_optimize_passes = (int)v;
+    } else if (k == "build.treelet_every") {
+        if (v < 0 || v > 32) return fail(PT_ERR_INVALID, "build.treelet_every must be in [0,32]");
+        ctx->build_treelet_every = (int)v;
     } else if (k == "build.max_levels") {
         if (v < 8 || v > 256) return fail(PT_ERR_INVALID, "build.max_levels must be in [8,256]");
         ctx->build_max_levels = (int)v;
@@ -877,7 +880,8 @@ int pt_scene_build(pt_context *ctx, const float *vtx, uint32_t n_vtx, const int3
         ctx->stream, (const float *)d_vtx, (const int32_t *)d_idx, n_tri, n_leaves,
         (const uint32_t *)first_leaf.ptr, link_encoding, scratch,
         (const int32_t *)d_mid, (float4 *)d_nodes, (float4 *)d_wn, (float4 *)d_wt, (float4 *)d_st,
-        ctx->build_ploc_radius, ctx->build_optimize_passes, ctx->build_max_levels);
+        ctx->build_ploc_radius, ctx->build_optimize_passes, ctx->build_treelet_every,
+        ctx->build_max_levels);
     (void)hipStreamSynchronize(ctx->stream);
     scratch.release();
     first_leaf.release();

@@ -35,7 +35,8 @@ DeviceBuildResult plan_triangle_splits(hipStream_t st, const float *d_vtx, const
 // d_stris is null).
 // ploc_radius 0: binary
 // radix tree over the Morton codes; > 0: locally-ordered clustering with that search radius.
-// optimize_passes > 0: that many rounds of parallel insertion-based optimisation of the tree.
+// optimize_passes > 0: that many rounds of parallel insertion-based optimisation of the tree;
+// treelet_every > 0: a round of treelet restructuring after every so many of them.
 // max_levels: an optimised tree deeper than this (at most 256) is given up for the radix tree,
 // whose depth the key length bounds.
 // Blocks until done.
@@ -44,6 +45,6 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
                                         uint32_t link_encoding, DeviceBuffer &scratch,
                                         const int32_t *d_mat_ids, float4 *d_nodes,
                                         float4 *d_wnodes, float4 *d_wtris, float4 *d_stris,
-                                        int ploc_radius, int optimize_passes, int max_levels = 256);
+                                        int ploc_radius, int optimize_passes, int treelet_every, int max_levels = 256);
 
 } // namespace mipt

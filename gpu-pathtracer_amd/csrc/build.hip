@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <vector>
+#include <string>
 
 #include "build.h"
 
@@ -626,11 +627,21 @@ __global__ __launch_bounds__(kB) void k_ploc_emit(PlocEmitArgs a) {
 // Boxes, depths and the level lists are recomputed between passes.  Every step is
 // deterministic (max is order independent), and nothing is handed between threads of a launch.
 constexpr int kUMaxDepth = 256;
+// Neither kind of pass bounds the depth of the tree; where triangles crowd (fans of slivers) the
+// cheapest arrangement is a chain.  Past this depth a node is not moved further down and the
+// subtree below a node is not rearranged, which keeps such chains from growing pass after pass.
+#ifndef PT_U_SOFT_DEPTH
+#define PT_U_SOFT_DEPTH 72
+#endif
 constexpr int kURounds = 4;          // bidding rounds of a pass (at most 15: four bits of the bid)
+#ifndef PT_U_SEARCH_CAP
+#define PT_U_SEARCH_CAP 512          // nodes one search may look at
+#endif
 
 struct UTree {
     PlocNodes t;
     int32_t *parent;
+    uint32_t *height;    // levels below an inner node (a leaf: 0, not stored)
     uint32_t n;          // leaves
     uint32_t total;      // 2n-1
     int32_t root;
@@ -714,6 +725,7 @@ __global__ __launch_bounds__(kB) void k_u_refit_level(const uint32_t *level_ids,
     u.t.box[2 * (size_t)id + 0] = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), 0.f);
     u.t.box[2 * (size_t)id + 1] = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.f);
     u.t.size[id] = u.t.size[l] + u.t.size[r];
+    u.height[id] = 1 + max(l < u.n ? 0u : u.height[l], r < u.n ? 0u : u.height[r]);
 }
 
 // pre-order positions of the children of one level's inner nodes (shallowest level first)
@@ -731,8 +743,8 @@ __global__ __launch_bounds__(kB) void k_u_place_level(const uint32_t *level_ids,
     u.t.before[r] = b + u.t.size[l];
 }
 
-__global__ __launch_bounds__(kB) void k_u_search(UTree u, int32_t *target, float *gain,
-                                                 uint32_t *state) {
+__global__ __launch_bounds__(kB) void k_u_search(UTree u, const uint32_t *depth, int32_t *target,
+                                                 float *gain, uint32_t *state) {
     const uint32_t x = blockIdx.x * kB + threadIdx.x;
     if (x >= u.total) return;
     target[x] = -1;
@@ -743,48 +755,75 @@ __global__ __launch_bounds__(kB) void k_u_search(UTree u, int32_t *target, float
     const float4 xlo = u.t.box[2 * (size_t)x], xhi = u.t.box[2 * (size_t)x + 1];
     const float ax = box_area(xlo, xhi);
     const float here = box_area(u.t.box[2 * (size_t)p], u.t.box[2 * (size_t)p + 1]);
-    float best = here;
+    // x ends up one level below where y is now, and so does everything below y
+    const uint32_t hx = x < u.n ? 0u : u.height[x];
+    const uint32_t deepest_y = max(depth[x], (uint32_t)PT_U_SOFT_DEPTH - min(hx, (uint32_t)PT_U_SOFT_DEPTH - 1)) - 1;
+    // Climb from x: at each ancestor c (the pivot) look into the subtree of c's other child.
+    // Taking x out frees its parent and shrinks the ancestors below the pivot to the union of
+    // the siblings passed on the way (`without`); `saved` is what that gives back so far.  The
+    // pivot and everything above hold x before and after.  Putting x next to y costs the area of
+    // the new pair plus what the nodes between the pivot and y grow by.
+    float best_gain = 0.f;
     int32_t best_y = -1;
     constexpr int kStack = 64;
     int32_t st_node[kStack];
     float st_ind[kStack];
-    int sp = 0;
-    {   // the root cannot be chosen (nothing is put above it); start with its children
-        st_node[0] = u.t.right[u.root]; st_ind[0] = 0.f;
-        st_node[1] = u.t.left[u.root];  st_ind[1] = 0.f;
-        // what the root grows by if x goes below it: nothing, x is inside it already
-        sp = 2;
-    }
+    float saved = here;
+    float4 wlo = xlo, whi = xhi;                   // set at the first pivot
     int visited = 0;
-    while (sp > 0 && visited < 4096) {
-        --sp;
-        const int32_t y = st_node[sp];
-        const float ind = st_ind[sp];
-        if (ind + ax >= best || y == (int32_t)x) continue;
-        ++visited;
-        const float4 ylo = u.t.box[2 * (size_t)y], yhi = u.t.box[2 * (size_t)y + 1];
-        const float direct = union_area(ylo, yhi, xlo, xhi);
-        const float total = ind + direct;
-        if (total < best && y != p) {
-            best = total;
-            best_y = y;
-        }
-        if ((uint32_t)y >= u.n) {
-            const float down = ind + (direct - box_area(ylo, yhi));
-            if (down + ax < best && sp + 2 <= kStack) {
-                // the child whose box grows less by x is looked at first
-                const int32_t l = u.t.left[y], r = u.t.right[y];
-                const float gl = union_area(u.t.box[2 * (size_t)l], u.t.box[2 * (size_t)l + 1], xlo, xhi);
-                const float gr = union_area(u.t.box[2 * (size_t)r], u.t.box[2 * (size_t)r + 1], xlo, xhi);
-                const bool left_first = gl <= gr;
-                st_node[sp] = left_first ? r : l; st_ind[sp] = down; ++sp;
-                st_node[sp] = left_first ? l : r; st_ind[sp] = down; ++sp;
+    int32_t below = (int32_t)x;
+    for (int32_t c = p, k = 1; c >= 0 && visited < PT_U_SEARCH_CAP; below = c, c = u.parent[c], ++k) {
+        const int32_t o = u.t.left[c] == below ? u.t.right[c] : u.t.left[c];
+        const float4 olo = u.t.box[2 * (size_t)o], ohi = u.t.box[2 * (size_t)o + 1];
+        int sp = 0;
+        st_node[sp] = o; st_ind[sp] = 0.f; ++sp;
+        while (sp > 0 && visited < PT_U_SEARCH_CAP) {
+            --sp;
+            const int32_t y = st_node[sp];
+            const float ind = st_ind[sp];
+            if (ind + ax >= saved - best_gain || depth[y] > deepest_y) continue;
+            ++visited;
+            const float4 ylo = u.t.box[2 * (size_t)y], yhi = u.t.box[2 * (size_t)y + 1];
+            const float direct = union_area(ylo, yhi, xlo, xhi);
+            const float total = ind + direct;
+            const bool pushes_too_deep =
+                depth[y] + 1 + ((uint32_t)y < u.n ? 0u : u.height[y]) > (uint32_t)PT_U_SOFT_DEPTH;
+            if (saved - total > best_gain && !(k == 1 && y == o) && !pushes_too_deep) {   // its own sibling: no move
+                best_gain = saved - total;
+                best_y = y;
+            }
+            if ((uint32_t)y >= u.n) {
+                const float down = ind + (direct - box_area(ylo, yhi));
+                if (down + ax < saved - best_gain && sp + 2 <= kStack) {
+                    // the child whose box grows less by x is looked at first
+                    const int32_t l = u.t.left[y], r = u.t.right[y];
+                    const float gl = union_area(u.t.box[2 * (size_t)l], u.t.box[2 * (size_t)l + 1], xlo, xhi);
+                    const float gr = union_area(u.t.box[2 * (size_t)r], u.t.box[2 * (size_t)r + 1], xlo, xhi);
+                    const bool left_first = gl <= gr;
+                    st_node[sp] = left_first ? r : l; st_ind[sp] = down; ++sp;
+                    st_node[sp] = left_first ? l : r; st_ind[sp] = down; ++sp;
+                }
             }
         }
+        if (k == 1) {
+            wlo = olo; whi = ohi;
+        } else {
+            wlo = make_float4(fminf(wlo.x, olo.x), fminf(wlo.y, olo.y), fminf(wlo.z, olo.z), 0.f);
+            whi = make_float4(fmaxf(whi.x, ohi.x), fmaxf(whi.y, ohi.y), fmaxf(whi.z, ohi.z), 0.f);
+            const float shrunk = box_area(wlo, whi);
+            // next to the pivot itself (not above the root): the new pair has the pivot's box,
+            // the pivot keeps what is left without x
+            if (c != u.root && saved - shrunk > best_gain &&
+                depth[c] + 1 + u.height[c] <= (uint32_t)PT_U_SOFT_DEPTH) {
+                best_gain = saved - shrunk;
+                best_y = c;
+            }
+            saved += box_area(u.t.box[2 * (size_t)c], u.t.box[2 * (size_t)c + 1]) - shrunk;
+        }
     }
-    if (best_y >= 0 && best < here * 0.9999f) {
+    if (best_y >= 0 && best_gain > here * 1e-4f) {
         target[x] = best_y;
-        gain[x] = here - best;
+        gain[x] = best_gain;
         state[x] = 1;
     }
 }
@@ -883,6 +922,174 @@ __global__ __launch_bounds__(kB) void k_u_apply(UTree u, const int32_t *target,
     u.parent[y] = p;
 }
 
+// ---- treelet restructuring --------------------------------------------------------------------
+// After Karras & Aila 2013 ("Fast parallel construction of high-quality bounding volume
+// hierarchies").  The other neighbourhood: where the insertion passes move one subtree at a
+// time, this one takes the top of the subtree below a node — the node and, largest box first, up
+// to five of its descendants, leaving seven subtrees hanging below them — and rebuilds those six
+// nodes into the arrangement of the seven subtrees with the least total surface area, found by
+// dynamic programming over the 127 subsets.  Leaves stay single triangles, so the cost of the
+// subtrees themselves does not enter.  Nodes of one depth are roots of disjoint subtrees; the
+// levels run deepest first, one launch each, so a node's treelet is rebuilt after those of the
+// nodes inside it.  One wave per workgroup: the tables of the 64 lanes sit side by side in LDS,
+// every lane enumerating the same subsets in the same order.
+constexpr int kTreeletLeaves = 7;
+constexpr int kTreeletSets = 1 << kTreeletLeaves;
+constexpr int kTreeletBlock = 64;
+
+__global__ __launch_bounds__(kTreeletBlock) void k_u_treelet(const uint32_t *level_ids, uint32_t count,
+                                                             uint32_t level, UTree u,
+                                                             unsigned int *changed) {
+    __shared__ float s_cost[kTreeletSets][kTreeletBlock];
+    __shared__ uint8_t s_part[kTreeletSets][kTreeletBlock];
+    const uint32_t k = blockIdx.x * kTreeletBlock + threadIdx.x;
+    const int lane = threadIdx.x;
+    if (k >= count) return;
+    const int32_t r = (int32_t)level_ids[k];
+    if ((uint32_t)r < u.n || u.t.size[r] < 3) return;
+    if (level + u.height[r] + 4 > PT_U_SOFT_DEPTH) return;          // a rearrangement can add four levels
+
+    // the treelet: seven subtrees (fewer near the bottom) and the nodes above them
+    int32_t leaf[kTreeletLeaves], inner[kTreeletLeaves - 1];
+    float larea[kTreeletLeaves];
+    auto area_of = [&](int32_t id) {
+        return box_area(u.t.box[2 * (size_t)id], u.t.box[2 * (size_t)id + 1]);
+    };
+#pragma unroll
+    for (int i = 0; i < kTreeletLeaves; ++i) { leaf[i] = -1; larea[i] = -1.f; }
+#pragma unroll
+    for (int i = 0; i < kTreeletLeaves - 1; ++i) inner[i] = -1;
+    inner[0] = r;
+    leaf[0] = u.t.left[r];  larea[0] = (uint32_t)leaf[0] >= u.n ? area_of(leaf[0]) : -1.f;
+    leaf[1] = u.t.right[r]; larea[1] = (uint32_t)leaf[1] >= u.n ? area_of(leaf[1]) : -1.f;
+    int m = 2;
+    float current = area_of(r);
+    for (int step = 0; step < kTreeletLeaves - 2; ++step) {
+        int pick = -1;
+        float best = -1.f;
+#pragma unroll
+        for (int i = 0; i < kTreeletLeaves; ++i)
+            if (larea[i] > best) { best = larea[i]; pick = i; }
+        if (pick < 0) break;                       // only triangles left
+        int32_t node = -1;
+#pragma unroll
+        for (int i = 0; i < kTreeletLeaves; ++i) if (i == pick) node = leaf[i];
+        const int32_t a = u.t.left[node], b = u.t.right[node];
+        const float aa = (uint32_t)a >= u.n ? area_of(a) : -1.f;
+        const float ab = (uint32_t)b >= u.n ? area_of(b) : -1.f;
+        current += best;
+#pragma unroll
+        for (int i = 0; i < kTreeletLeaves; ++i) {
+            if (i == pick) { leaf[i] = a; larea[i] = aa; }
+            if (i == m) { leaf[i] = b; larea[i] = ab; }
+        }
+#pragma unroll
+        for (int i = 0; i < kTreeletLeaves - 1; ++i) if (i == m - 1) inner[i] = node;
+        ++m;
+    }
+    if (m < 3) return;
+
+    float lo[kTreeletLeaves][3], hi[kTreeletLeaves][3];
+    uint32_t lsize[kTreeletLeaves];
+#pragma unroll
+    for (int i = 0; i < kTreeletLeaves; ++i) {
+        const bool have = i < m;
+        const float4 l4 = have ? u.t.box[2 * (size_t)leaf[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 h4 = have ? u.t.box[2 * (size_t)leaf[i] + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        lo[i][0] = l4.x; lo[i][1] = l4.y; lo[i][2] = l4.z;
+        hi[i][0] = h4.x; hi[i][1] = h4.y; hi[i][2] = h4.z;
+        lsize[i] = have ? u.t.size[leaf[i]] : 0u;
+    }
+    auto box_of = [&](int s, float4 &blo, float4 &bhi) {
+        float l0 = 3.0e38f, l1 = 3.0e38f, l2 = 3.0e38f, h0 = -3.0e38f, h1 = -3.0e38f, h2 = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < kTreeletLeaves; ++i) {
+            const bool in = (s >> i) & 1;
+            l0 = in ? fminf(l0, lo[i][0]) : l0; l1 = in ? fminf(l1, lo[i][1]) : l1; l2 = in ? fminf(l2, lo[i][2]) : l2;
+            h0 = in ? fmaxf(h0, hi[i][0]) : h0; h1 = in ? fmaxf(h1, hi[i][1]) : h1; h2 = in ? fmaxf(h2, hi[i][2]) : h2;
+        }
+        blo = make_float4(l0, l1, l2, 0.f);
+        bhi = make_float4(h0, h1, h2, 0.f);
+    };
+
+    // least total area of the nodes that arrange subset s, s ascending: every proper subset of s
+    // is a smaller number.  The lowest member stays on one side, so each split is seen once.
+    const int full = (1 << m) - 1;
+    for (int s = 1; s <= full; ++s) {
+        if ((s & (s - 1)) == 0) {
+            s_cost[s][lane] = 0.f;
+            continue;
+        }
+        float4 blo, bhi;
+        box_of(s, blo, bhi);
+        const int low = s & -s, rest = s ^ low;
+        float best = 3.0e38f;
+        int best_p = low;
+        // (four splits a turn, so that their table reads are in flight together; a turn that runs
+        // past the last subset repeats the split with q = 0, which changes nothing)
+        for (int q = (rest - 1) & rest;;) {
+            const int q1 = (q - 1) & rest, q2 = (q1 - 1) & rest, q3 = (q2 - 1) & rest;
+            const int qa = q, qb = q ? q1 : 0, qc = q && q1 ? q2 : 0, qd = q && q1 && q2 ? q3 : 0;
+            const float ca = s_cost[low | qa][lane] + s_cost[rest ^ qa][lane];
+            const float cb = s_cost[low | qb][lane] + s_cost[rest ^ qb][lane];
+            const float cc = s_cost[low | qc][lane] + s_cost[rest ^ qc][lane];
+            const float cd = s_cost[low | qd][lane] + s_cost[rest ^ qd][lane];
+            if (ca < best) { best = ca; best_p = low | qa; }
+            if (cb < best) { best = cb; best_p = low | qb; }
+            if (cc < best) { best = cc; best_p = low | qc; }
+            if (cd < best) { best = cd; best_p = low | qd; }
+            if (qd == 0) break;
+            q = (qd - 1) & rest;
+        }
+        s_cost[s][lane] = box_area(blo, bhi) + best;
+        s_part[s][lane] = (uint8_t)best_p;
+    }
+    if (!(s_cost[full][lane] < current * 0.99999f)) return;
+    atomicAdd(changed, 1u);
+
+    // hand the six nodes out again, top down
+    int stack_set[kTreeletLeaves], stack_node[kTreeletLeaves];
+    int sp = 0, next = 1;
+    stack_set[0] = full; stack_node[0] = r; sp = 1;
+    while (sp > 0) {
+        --sp;
+        int s = 0;
+        int32_t node = -1;
+#pragma unroll
+        for (int i = 0; i < kTreeletLeaves; ++i) if (i == sp) { s = stack_set[i]; node = stack_node[i]; }
+        const int p = s_part[s][lane];
+        int32_t child[2];
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int t = side ? s ^ p : p;
+            int32_t c = -1;
+            if ((t & (t - 1)) == 0) {
+#pragma unroll
+                for (int i = 0; i < kTreeletLeaves; ++i) if (t == (1 << i)) c = leaf[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < kTreeletLeaves - 1; ++i) if (i == next) c = inner[i];
+                ++next;
+                float4 blo, bhi;
+                box_of(t, blo, bhi);
+                u.t.box[2 * (size_t)c] = blo;
+                u.t.box[2 * (size_t)c + 1] = bhi;
+                uint32_t size = 0;
+#pragma unroll
+                for (int i = 0; i < kTreeletLeaves; ++i) size += ((t >> i) & 1) ? lsize[i] : 0u;
+                u.t.size[c] = size;
+#pragma unroll
+                for (int i = 0; i < kTreeletLeaves; ++i) if (i == sp) { stack_set[i] = t; stack_node[i] = c; }
+                ++sp;
+            }
+            u.parent[c] = node;
+            child[side] = c;
+        }
+        u.t.left[node] = child[0];
+        u.t.right[node] = child[1];
+    }
+}
+
 inline unsigned int grid_for(uint64_t n) { return (unsigned int)((n + kB - 1) / kB); }
 
 #define BUILD_CHECK(expr)                                 \
@@ -902,7 +1109,7 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
                              uint32_t n, uint32_t enc, DeviceBuffer &scratch,
                              const int32_t *d_mat_ids, float4 *d_nodes,
                              float4 *d_wnodes, float4 *d_wtris, float4 *d_stris,
-                             int ploc_radius, int optimize_passes, int max_levels) {
+                             int ploc_radius, int optimize_passes, int treelet_every, int max_levels) {
     DeviceBuildResult res;
     const uint32_t n_inner = n - 1;
     // scratch carve-up
@@ -946,6 +1153,7 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
     // optimisation only
     const bool opt = optimize_passes > 0;
     const size_t o_uparent = opt ? take(4 * total_nodes) : 0;
+    const size_t o_uheight = opt ? take(4 * total_nodes) : 0;
     const size_t o_udepth = opt ? take(4 * total_nodes) : 0, o_udepth2 = opt ? take(4 * total_nodes) : 0;
     const size_t o_uids = opt ? take(4 * total_nodes) : 0, o_uids2 = opt ? take(4 * total_nodes) : 0;
     const size_t o_utarget = opt ? take(4 * total_nodes) : 0, o_ugain = opt ? take(4 * total_nodes) : 0;
@@ -979,6 +1187,7 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
         UTree u;
         u.t = t;
         u.parent = (int32_t *)(base + o_uparent);
+        u.height = (uint32_t *)(base + o_uheight);
         u.n = n;
         u.total = (uint32_t)total_nodes;
         u.root = root;
@@ -1021,11 +1230,25 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
             }
             return hipGetLastError();
         };
-        for (int pass = 0; pass < optimize_passes; ++pass) {
+        std::string schedule;                                      // I: insertion pass, T: treelet pass
+        for (int i = 1; i <= optimize_passes; ++i) {
+            schedule += 'I';
+            if (treelet_every > 0 && i % treelet_every == 0) schedule += 'T';
+        }
+        for (size_t pass = 0; pass < schedule.size(); ++pass) {
             const hipError_t e = levels_and_refit();
             if (e == hipErrorInvalidValue) break;                  // keep the tree as it is now
             BUILD_CHECK(e);
-            hipLaunchKernelGGL(k_u_search, dim3(g_all), dim3(kB), 0, st, u, target, gain, udepth2);
+            if (schedule[pass] == 'T') {
+                for (int d = deepest; d >= 0; --d) {
+                    const uint32_t cnt = begin[d + 1] - begin[d];
+                    if (cnt)
+                        hipLaunchKernelGGL(k_u_treelet, dim3((cnt + kTreeletBlock - 1) / kTreeletBlock),
+                                           dim3(kTreeletBlock), 0, st, uids2 + begin[d], cnt, (uint32_t)d, u, uflags + 2);
+                }
+                continue;
+            }
+            hipLaunchKernelGGL(k_u_search, dim3(g_all), dim3(kB), 0, st, u, udepth, target, gain, udepth2);
             BUILD_CHECK(hipMemsetAsync(lock, 0, 8 * total_nodes, st));
             for (int round = 0; round < kURounds; ++round) {
                 hipLaunchKernelGGL(k_u_lock, dim3(g_all), dim3(kB), 0, st, u, target, gain, udepth2, round, lock);
@@ -1247,19 +1470,20 @@ DeviceBuildResult build_scene_on_device(hipStream_t st, const float *d_vtx, cons
                                         uint32_t enc, DeviceBuffer &scratch,
                                         const int32_t *d_mat_ids, float4 *d_nodes,
                                         float4 *d_wnodes, float4 *d_wtris, float4 *d_stris,
-                                        int ploc_radius, int optimize_passes, int max_levels) {
+                                        int ploc_radius, int optimize_passes, int treelet_every,
+                                        int max_levels) {
     max_levels = std::min(std::max(max_levels, 2), kUMaxDepth);
     if (n_leaves == n_tris) d_first = nullptr;
     DeviceBuildResult res = build_once(st, d_vtx, d_idx, n_tris, d_first, n_leaves, enc, scratch, d_mat_ids,
                                        d_nodes, d_wnodes, d_wtris, d_stris, ploc_radius, optimize_passes,
-                                       max_levels);
+                                       treelet_every, max_levels);
     // The optimisation passes can, on contrived input, make a tree deeper than their level
     // lists reach; the radix tree cannot (its depth is bounded by the key length), so it
     // is the answer then.  The inputs are untouched and every output is written again.
     if (res.too_deep && (ploc_radius > 0 || optimize_passes > 0)) {
         (void)hipGetLastError();
         res = build_once(st, d_vtx, d_idx, n_tris, d_first, n_leaves, enc, scratch, d_mat_ids, d_nodes,
-                         d_wnodes, d_wtris, d_stris, 0, 0, max_levels);
+                         d_wnodes, d_wtris, d_stris, 0, 0, 0, max_levels);
     }
     return res;
 }

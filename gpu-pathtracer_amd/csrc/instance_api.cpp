@@ -264,7 +264,8 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
                 build_scene_on_device(ctx->stream, mv, mi, d.n_triangles, pl.n_leaves,
                                       (const uint32_t *)pl.first_leaf.ptr, link_encoding, scratch,
                                       nullptr, mn, mw, mt, nullptr, ctx->build_ploc_radius,
-                                      ctx->build_optimize_passes, ctx->build_max_levels);
+                                      ctx->build_optimize_passes, ctx->build_treelet_every,
+                                      ctx->build_max_levels);
             hipError_t err = br.hip_error;
             if (err == hipSuccess && !br.no_memory && !br.bad_input) {
                 launch_rebase_children(ctx->stream, mw, pl.n_wnodes, pl.wnode, pl.wtri);

@@ -18,14 +18,18 @@ pytestmark = pytest.mark.gpu
                      "clustering_optimised"], autouse=True)
 def algorithm(request, gpu_ctx):
     """The GPU builders: the Morton radix tree (the default) and locally-ordered clustering,
-    each also followed by rounds of parallel insertion-based optimisation."""
+    each also followed by rounds of parallel insertion-based optimisation with treelet
+    restructuring between them (after every round on the radix tree, after the second on the
+    clustered one)."""
     gpu_ctx.set_option("build.ploc_radius", request.param[0])
     gpu_ctx.set_option("build.optimize_passes", request.param[1])
+    gpu_ctx.set_option("build.treelet_every", 1 if request.param[0] == 0 else 2)
     gpu_ctx.set_option("build.split_ratio", 0)           # one leaf per triangle: the tests with splits say so
     yield request.param
     gpu_ctx.set_option("build.ploc_radius", 0)
     gpu_ctx.set_option("build.optimize_passes", 0)
-    gpu_ctx.set_option("build.split_ratio", 4)           # the library's default
+    gpu_ctx.set_option("build.treelet_every", 3)         # the library's defaults
+    gpu_ctx.set_option("build.split_ratio", 4)
 
 
 def _check_tree(mipt, oracle, nodes, vtx, idx, enc):
@@ -153,6 +157,42 @@ def test_optimisation_passes_improve_the_tree(mipt, scenes, gpu_ctx, algorithm):
         # the nearest distance does not depend on the tree; which of two triangles at one distance
         # is reported may
         np.testing.assert_array_equal(h["uvwt"][:, 3], hits[0]["uvwt"][:, 3])
+
+
+def test_treelet_rounds_improve_the_tree(mipt, oracle, scenes, gpu_ctx, algorithm):
+    """build.treelet_every: the rounds of treelet restructuring between the insertion rounds give
+    a valid tree over the same leaf boxes with a smaller surface-area sum and fewer box tests per
+    ray, and the hits stay the oracle's on the tree read back."""
+    if algorithm != (0, 0):
+        pytest.skip("sets the options itself")
+    vtx, idx, _, _ = scenes.clutter(120_000, seed=9)
+    rays = scenes.surface_rays(vtx, idx, 1 << 16, seed=4).astype(mipt.ray_dtype)
+
+    def area_sum(nodes):
+        raw = nodes.view(np.float32).reshape(-1, 8)
+        e = raw[:, 4:7].astype(np.float64) - raw[:, 0:3].astype(np.float64)
+        a = e[:, 0] * e[:, 1] + e[:, 0] * e[:, 2] + e[:, 1] * e[:, 2]
+        return float(a[raw[:, 3].view(np.int32) < 0].sum() / a[0])
+
+    cost, boxes = {}, {}
+    try:
+        gpu_ctx.set_option("build.optimize_passes", 4)
+        for every in (0, 1, 4):
+            gpu_ctx.set_option("build.treelet_every", every)
+            sc = mipt.Scene(gpu_ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
+            try:
+                nodes = sc.read_nodes()
+                _check_tree(mipt, oracle, nodes, vtx, idx, mipt.PT_LINKS_INT_BITS)
+                got, st = sc.trace_closest(rays, stats=True)
+                assert len(same_hits(got, oracle.closest(nodes, vtx, idx, rays, nthreads=8, int_bits=True), True)) == 0
+                cost[every], boxes[every] = area_sum(nodes), st.box_tests / rays.shape[0]
+            finally:
+                sc.close()
+    finally:
+        gpu_ctx.set_option("build.optimize_passes", 0)
+        gpu_ctx.set_option("build.treelet_every", 3)
+    assert cost[1] < cost[4] < cost[0], cost
+    assert boxes[1] < boxes[0] and boxes[4] < boxes[0], boxes
 
 
 def _levels(nodes):

@@ -17,6 +17,8 @@ for a in sys.argv[1:]:
 gen = scenes.displaced_cube_sphere if os.environ.get("SCENE", "uv") == "cube" else scenes.displaced_sphere
 vtx, idx, _, _ = gen(int(os.environ.get("TRIS", "28000000")), seed=7)
 ctx.set_option("build.optimize_passes", int(os.environ.get("PASSES", "8")))
+if "TREELET" in os.environ:
+    ctx.set_option("build.treelet_every", int(os.environ["TREELET"]))
 import time
 ctx.synchronize()
 _t0 = time.perf_counter()
