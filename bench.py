@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--scene", default=None, help="OBJ / glTF / GLB file to render instead of the stand-in")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=INT",
                     help="pt_context_set_option tuning knob, e.g. extend.persistent=0")
+    ap.add_argument("--bvh", choices=("host", "gpu"), default="host",
+                    help="host: bvh::build_bvh's counterpart pt_bvh_build (binned SAH + 2 insertion rounds) and "
+                         "pt_scene_create; gpu: pt_scene_build (radix tree + insertion and treelet rounds)")
     ap.add_argument("--bvh-option", action="append", default=[], metavar="KEY=VALUE",
                     help="extra pt_bvh_options_set pairs for the host BVH build (e.g. mipt.optimize_passes=2)")
     ap.add_argument("--nee", action="store_true",
@@ -229,7 +232,9 @@ def main():
     bvh_opts.update(dict(o.split("=", 1) for o in args.bvh_option))
     link_enc = mipt.PT_LINKS_INT_BITS if bvh_opts.get("mipt.link_encoding") == "int" else mipt.PT_LINKS_FLOAT_VALUE
     leaf_bounds = mipt.mesh_leaf_bounds(vtx, idx)
-    if world > 1:
+    if args.bvh == "gpu":
+        nodes, bvh_source = None, "built on the GPU by this process (pt_scene_build)"
+    elif world > 1:
         nodes, bvh_source = D.build_bvh_once(leaf_bounds, mipt.bvh_options(**bvh_opts), rank)
     else:
         nodes = mipt.build_bvh(leaf_bounds, mipt.bvh_options(**bvh_opts))
@@ -242,7 +247,16 @@ def main():
     for opt in args.option:
         key, _, val = opt.partition("=")
         ctx.set_option(key, int(val))
+    if nodes is None:
+        ctx.set_option("build.optimize_passes", 8)
+        ctx.synchronize()
+        t0 = time.time()
     scene = mipt.Scene(ctx, nodes, vtx, idx, mats, mids, link_encoding=link_enc)
+    if nodes is None:
+        ctx.synchronize()
+        build_s = time.time() - t0
+        ctx.set_option("build.optimize_passes", 0)
+        nodes = scene.read_nodes()          # what the CPU legs walk
     W, H, spp = args.width, args.height, args.spp_per_step
     cam = make_camera(W / H)
     film_t = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")

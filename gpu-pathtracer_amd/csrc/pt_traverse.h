@@ -1318,7 +1318,17 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
                     const uint32_t ri = perm ? perm[idx] : idx;
                     const float4 ro = reinterpret_cast<const float4 *>(rays + ri)[0];
                     const float4 rd = reinterpret_cast<const float4 *>(rays + ri)[1];
-                    if constexpr (ANY) any_begin(st, ro, rd, stack, any_exact, root);
+                    // A ray that does not move along an axis (1/d infinite) and lies exactly in a bounding plane
+                    // of a box misses that box in the reference's slab test (0 * inf is a NaN on
+                    // one side of the slab only) but not a flat leaf box in the same plane inside it
+                    // (NaN on both sides: the slab is skipped), and the Moller-Trumbore test then
+                    // reports a hit for a ray in the triangle's plane (every comparison with its
+                    // NaNs is false).  The coarse boxes of the four-child walk cannot tell: such
+                    // occlusion rays go to the fixed order.  (The watertight test turns a ray in
+                    // the triangle's plane down, so closest hits are not affected.)
+                    const bool axis_ray = QUAD && ANY && !(fabsf(1.0f / rd.x) < INFINITY && fabsf(1.0f / rd.y) < INFINITY &&
+                                                   fabsf(1.0f / rd.z) < INFINITY);
+                    if constexpr (ANY) any_begin(st, ro, rd, stack, any_exact || axis_ray, root);
                     else ordered_begin(st, ro, rd, stack, root);
                     if constexpr (QUAD) coarse_ray_terms(st, cmax);
                     my_ray = ri;

@@ -221,7 +221,19 @@ def test_awkward_rays_match_the_oracle(mipt, oracle, scenes, gpu_ctx):
             got, st = sc.trace_closest(rays, stats=True)
             assert len(same_hits(got, want)) == 0
             assert st.tie_rays > 100_000 and 0.6 < (got["primid"] >= 0).mean() < 0.95
-        np.testing.assert_array_equal(sc.trace_any(rays), oracle.any_hit(nodes, vtx, idx, rays, nthreads=16))
+        want_any = oracle.any_hit(nodes, vtx, idx, rays, nthreads=16)
+        np.testing.assert_array_equal(sc.trace_any(rays), want_any)
+        # The four-child walk (what scenes beyond the caches get) on the same rays.  Occlusion
+        # rays along an axis are the case its coarse boxes cannot decide: a ray lying in a
+        # bounding plane of an inner box misses that box in the reference (0 * inf on one side of
+        # the slab) but not a flat leaf box in the same plane, where the Moller-Trumbore test
+        # then reports a hit.
+        gpu_ctx.set_option("extend.quad", 1)
+        try:
+            assert len(same_hits(sc.trace_closest(rays), want)) == 0
+            np.testing.assert_array_equal(sc.trace_any(rays), want_any)
+        finally:
+            gpu_ctx.set_option("extend.quad", -1)
         # the shader's Moller-Trumbore closest hit clamps the distance with max(0, t): +0 for t = -0
         mt = sc.trace_closest(rays, mipt.PT_TRACE_MOLLER_TRUMBORE)
         want_mt = oracle.closest(nodes, vtx, idx, rays, nthreads=16, moller_trumbore=True)
@@ -229,6 +241,27 @@ def test_awkward_rays_match_the_oracle(mipt, oracle, scenes, gpu_ctx):
         assert (mt["uvwt"][:, 3].view(np.uint32) == 0x80000000).sum() == 0
     finally:
         gpu_ctx.set_option("extend.persistent", 1)
+        sc.close()
+
+
+def test_awkward_rays_in_a_box_of_axis_aligned_walls(mipt, oracle, scenes, gpu_ctx):
+    """The same kinds of rays in the Cornell box, where every surface lies in an axis plane and
+    every box of the tree has faces in those planes: closest hits and occlusion, two-child and
+    four-child walk."""
+    vtx, idx, _, _ = scenes.cornell_box()
+    nodes = mipt.build_bvh(mipt.mesh_leaf_bounds(vtx, idx), mipt.bvh_options(**{"bvh.builder": "sah"}))
+    rays = scenes.awkward_rays(vtx, idx, 1 << 18, seed=44).astype(mipt.ray_dtype)
+    sc = mipt.Scene(gpu_ctx, nodes, vtx, idx)
+    try:
+        want = oracle.closest(nodes, vtx, idx, rays, nthreads=16)
+        want_any = oracle.any_hit(nodes, vtx, idx, rays, nthreads=16)
+        assert 0.05 < want_any.mean() < 0.99
+        for quad in (0, 1):
+            gpu_ctx.set_option("extend.quad", quad)
+            assert len(same_hits(sc.trace_closest(rays), want)) == 0
+            np.testing.assert_array_equal(sc.trace_any(rays), want_any)
+    finally:
+        gpu_ctx.set_option("extend.quad", -1)
         sc.close()
 
 

@@ -27,8 +27,12 @@ def by_scale(nodes):
 
 
 ctx = mipt.Context(0)
-gen = scenes.displaced_cube_sphere if os.environ.get("SCENE", "cube") == "cube" else scenes.displaced_sphere
-vtx, idx, _, _ = gen(int(os.environ.get("TRIS", "2000000")), seed=7)
+SCENE = os.environ.get("SCENE", "cube")
+if SCENE == "atrium":                         # the headline benchmark's scene
+    vtx, idx, _, _ = scenes.atrium(int(os.environ.get("TRIS", "262144")), seed=42)
+else:
+    gen = scenes.displaced_cube_sphere if SCENE == "cube" else scenes.displaced_sphere
+    vtx, idx, _, _ = gen(int(os.environ.get("TRIS", "2000000")), seed=7)
 rays = scenes.surface_rays(vtx, idx, 1 << 20, seed=7)
 d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
 d_h = torch.empty_like(d_r)
