@@ -754,7 +754,6 @@ __global__ __launch_bounds__(kB) void k_u_search(UTree u, const uint32_t *depth,
     if (p == u.root) return;                       // the root's children stay where they are
     const float4 xlo = u.t.box[2 * (size_t)x], xhi = u.t.box[2 * (size_t)x + 1];
     const float ax = box_area(xlo, xhi);
-    const float here = box_area(u.t.box[2 * (size_t)p], u.t.box[2 * (size_t)p + 1]);
     // x ends up one level below where y is now, and so does everything below y
     const uint32_t hx = x < u.n ? 0u : u.height[x];
     const uint32_t deepest_y = max(depth[x], (uint32_t)PT_U_SOFT_DEPTH - min(hx, (uint32_t)PT_U_SOFT_DEPTH - 1)) - 1;
@@ -768,15 +767,27 @@ __global__ __launch_bounds__(kB) void k_u_search(UTree u, const uint32_t *depth,
     constexpr int kStack = 64;
     int32_t st_node[kStack];
     float st_ind[kStack];
-    float saved = here;
-    float4 wlo = xlo, whi = xhi;                   // set at the first pivot
+    float saved = 0.f, here = 0.f;                 // set at the first pivot, like `without`
+    float4 wlo = xlo, whi = xhi;
+    float4 clo = xlo, chi = xhi;                   // box of the node the climb comes from
     int visited = 0;
     int32_t below = (int32_t)x;
     for (int32_t c = p, k = 1; c >= 0 && visited < PT_U_SEARCH_CAP; below = c, c = u.parent[c], ++k) {
         const int32_t o = u.t.left[c] == below ? u.t.right[c] : u.t.left[c];
         const float4 olo = u.t.box[2 * (size_t)o], ohi = u.t.box[2 * (size_t)o + 1];
+        // the pivot's box is the union of its children's (the boxes are tight)
+        clo = make_float4(fminf(clo.x, olo.x), fminf(clo.y, olo.y), fminf(clo.z, olo.z), 0.f);
+        chi = make_float4(fmaxf(chi.x, ohi.x), fmaxf(chi.y, ohi.y), fmaxf(chi.z, ohi.z), 0.f);
+        const float area_c = box_area(clo, chi);
+        if (k == 1) saved = here = area_c;
         int sp = 0;
-        st_node[sp] = o; st_ind[sp] = 0.f; ++sp;
+        {   // most pivots end here: neither next to o nor anywhere below it
+            const float direct = union_area(olo, ohi, xlo, xhi);
+            const float room = saved - best_gain;
+            if (direct < room || (direct - box_area(olo, ohi)) + ax < room) {
+                st_node[sp] = o; st_ind[sp] = 0.f; ++sp;
+            }
+        }
         while (sp > 0 && visited < PT_U_SEARCH_CAP) {
             --sp;
             const int32_t y = st_node[sp];
@@ -818,7 +829,7 @@ __global__ __launch_bounds__(kB) void k_u_search(UTree u, const uint32_t *depth,
                 best_gain = saved - shrunk;
                 best_y = c;
             }
-            saved += box_area(u.t.box[2 * (size_t)c], u.t.box[2 * (size_t)c + 1]) - shrunk;
+            saved += area_c - shrunk;
         }
     }
     if (best_y >= 0 && best_gain > here * 1e-4f) {
