@@ -120,7 +120,7 @@ ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bo
     const DeviceScene &d = scene->dev;
     const bool two_level = d.tlas != nullptr;
     const bool shallow = !two_level && d.wide_depth <= PT_CACHE_MAX_TREE_DEPTH;
-    const uint64_t scene_bytes = 64ull * d.n_wnodes + 48ull * d.n_tri;
+    const uint64_t scene_bytes = 64ull * d.n_wnodes + 48ull * (two_level ? d.n_mesh_records : d.n_tri);
     const bool beyond_caches = scene_bytes > (256ull << 20);
     int stack = PT_LDS_STACK_ENTRIES, cache = 0;
     if (two_level) {
@@ -146,9 +146,9 @@ ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bo
     // 12.3 / 13.8 -> 11.1 / 11.9 ms; the bench scene, in the caches, loses 7 %).  A step pushes up to
     // three children, so the LDS goes to the stacks rather than to a copy of the top, and the
     // rays in flight no longer need thinning out: five workgroups per compute unit again.
-    if (d.qnodes && !two_level)
+    if (d.qnodes)
         c.quad = ctx->extend_quad >= 0 ? (ctx->extend_quad ? 1 : 0) : (beyond_caches ? 1 : 0);
-    if (c.quad && beyond_caches) {
+    if (c.quad && beyond_caches && !two_level) {
         stack = coherent ? PT_LDS_STACK_ENTRIES : 24;
         cache = coherent ? 0 : 96;
         if (ctx->extend_blocks_per_cu <= 0) c.blocks_per_cu = 5;

@@ -375,7 +375,12 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             di.tri_off = off[in.mesh].tri;
             di.n_tri = d.n_triangles;
             di.first_tri = first;
-            di._pad = 0;
+            {
+                const pt_bbox &rb = plan[in.mesh].root;
+                float c = 0.f;
+                for (int k = 0; k < 3; ++k) c = std::max(c, std::max(std::fabs(rb.pmin[k]), std::fabs(rb.pmax[k])));
+                di.cmax = c * 1.001f;
+            }
             moffs[i] = in.material_offset;
             std::memcpy(&fwd[12 * (size_t)i], in.object_to_world, sizeof(float) * 12);
             bool emissive = false;
@@ -448,6 +453,7 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
         d.n_nodes = (uint32_t)tot_nodes;
         d.n_tri = (uint32_t)total_tris;
         d.n_wnodes = (uint32_t)tot_wnodes;
+        d.n_mesh_records = (uint32_t)tot_wtris;
         d.n_materials = (uint32_t)mats.size();
         d.link_enc = link_encoding;
         d.wide_depth = wide_depth;
@@ -489,6 +495,37 @@ int pt_scene_create_instanced(pt_context *ctx, const pt_mesh_desc *meshes, uint3
             d.top_cache = (const float4 *)buf;
             d.top_global = index;
             d.n_top_cache = n_cached;
+        }
+        // The meshes' trees as four-child nodes with their 64-byte triangle records, for scenes
+        // whose mesh records come from memory rather than from the caches (option scene.quad; a
+        // scene it cannot be made for keeps the two-child form only).
+        if (ctx->scene_quad && tot_wnodes >= 1 && 4 * (uint64_t)tot_wtris < (1ull << 31)) {
+            void *qn = nullptr, *qt = nullptr, *flag = nullptr;
+            hipError_t err = hipDeviceSynchronize();            // the uploads above used the null stream
+            if (err == hipSuccess) err = hipMalloc(&qn, 64 * (size_t)tot_wnodes);
+            if (err == hipSuccess) err = hipMalloc(&qt, 64 * (size_t)tot_wtris);
+            if (err == hipSuccess) err = hipMalloc(&flag, 16);
+            uint32_t bad = 1;
+            if (err == hipSuccess) err = hipMemsetAsync(flag, 0, 16, ctx->stream);
+            if (err == hipSuccess) err = hipMemsetAsync(qt, 0, 64 * (size_t)tot_wtris, ctx->stream);
+            if (err == hipSuccess) {
+                launch_build_quad(ctx->stream, d.wnodes, (uint32_t)tot_wnodes, d.wtris, (uint32_t)tot_wtris,
+                                  (float4 *)qn, (float4 *)qt, (uint32_t *)flag);
+                err = hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream);
+            }
+            if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+            if (flag) (void)hipFree(flag);
+            if (err == hipSuccess && bad == 0) {
+                sc->allocs.push_back(qn);
+                sc->allocs.push_back(qt);
+                d.qnodes = (const float4 *)qn;
+                d.qtris = (const float4 *)qt;
+                if (needs_big_addresses(tot_wnodes, 4 * (uint64_t)tot_wtris / PT_TRI_RECORD_16B + 1)) d.big = 1;
+            } else {
+                (void)hipGetLastError();
+                if (qn) (void)hipFree(qn);
+                if (qt) (void)hipFree(qt);
+            }
         }
         d.instances = (const DeviceInstance *)upload(dinst.data(), sizeof(DeviceInstance) * dinst.size());
         d.n_tlas_nodes = n_top_nodes;

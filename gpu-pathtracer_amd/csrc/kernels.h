@@ -20,7 +20,8 @@ struct DeviceInstance {
     // nodes, traversal triangle records, vertices, triangles (of idx); then its triangle
     // count and the index of its first triangle in the world-space shading records.
     uint32_t node_off, wnode_off, wtri_off, vtx_off;
-    uint32_t tri_off, n_tri, first_tri, _pad;
+    uint32_t tri_off, n_tri, first_tri;
+    float cmax;           // largest coordinate of the mesh's root box, a little generous (four-child walk)
 };
 
 // Device-resident scene, passed to kernels by value.
@@ -43,6 +44,9 @@ struct DeviceScene {
     uint32_t n_lights;
     float light_area;
     uint32_t n_nodes, n_tri, n_wnodes, n_materials;
+    // two-level scenes: traversal triangle records of all meshes together (n_tri counts the
+    // instanced triangles there); 0 in single-level scenes, where every leaf has one
+    uint32_t n_mesh_records;
     uint32_t link_enc;
     uint32_t wide_depth;
     uint32_t big;          // wnodes or wtris reach beyond 4 GiB: records need 64-bit addresses
@@ -61,7 +65,8 @@ struct DeviceScene {
     // ascending.  Null where tri_leaf is set.
     const uint32_t *tri_leaf_first;
     const int32_t *tri_leaf_list;
-    // Single-level scenes below 4 GiB of records: the same tree with two levels folded into one,
+    // The same tree with two levels folded into one (of a two-level scene: the meshes' trees; the
+    // top-level tree has the two-child form only),
     // as 64-byte four-child nodes whose child boxes are 8-bit offsets on a per-node grid (never
     // inside the exact boxes), and 64-byte triangle records that carry the leaf's exact box.
     //   qnodes[4 i .. 4 i + 3], i = index of the two-child node the record was folded from:

@@ -514,6 +514,118 @@ __device__ __forceinline__ void any_begin(OrderedState &st, const float4 ro, con
     }
 }
 
+// One step at a four-child node whose record (f0, f1, f2: grid and child bytes, ch: the children)
+// the caller has read: tests the four decoded boxes, takes the nearest hit child and pushes the
+// others, farthest first; with no room for them the lane stops with the node itself on top of its
+// stack, as in the two-child step.
+template <bool COUNT>
+__device__ __forceinline__ void quad_node_step(OrderedState &st, int32_t *stack, int stack_cap,
+                                               const float4 f0, const float4 f1, const float4 f2,
+                                               const int4 ch, unsigned long long &nb) {
+    if (COUNT) nb += 4;
+    const uint32_t qlx = __float_as_uint(f1.z), qly = __float_as_uint(f1.w),
+                   qlz = __float_as_uint(f2.x), qhx = __float_as_uint(f2.y),
+                   qhy = __float_as_uint(f2.z), qhz = __float_as_uint(f2.w);
+    float key[4];
+    int32_t ref[4] = {ch.x, ch.y, ch.z, ch.w};
+    int nh = 0;
+    // The slab test of bvh.glslh:165-177 on the decoded boxes, with the min / max of
+    // the two planes of an axis taken by the sign of 1/d instead (one select per axis
+    // for the four children together): the same numbers wherever no product is a NaN
+    // (a decoded lo is never above its hi, and rounding is monotonic), and where one is
+    // (a ray inside a box plane with no extent along that axis) the plane drops out
+    // of the max3 / min3 -- which can only let the ray into a coarse box the
+    // reference's arithmetic would have kept it out of.  Not so for a leaf's exact
+    // box, whose test is the reference's as written (triangle step).
+    const bool sgx = __float_as_int(st.r.ix) < 0, sgy = __float_as_int(st.r.iy) < 0,
+               sgz = __float_as_int(st.r.iz) < 0;
+    const uint32_t qnx = sgx ? qhx : qlx, qfx = sgx ? qlx : qhx;
+    const uint32_t qny = sgy ? qhy : qly, qfy = sgy ? qly : qhy;
+    const uint32_t qnz = sgz ? qhz : qlz, qfz = sgz ? qlz : qhz;
+#ifndef PT_QUAD_REFERENCE_FORM
+    // see coarse_ray_terms
+    const float cax = f0.w * st.qax, cay = f1.x * st.qay, caz = f1.y * st.qaz;
+    const float cbx = (f0.x - st.r.ox) * st.qax, cby = (f0.y - st.r.oy) * st.qay,
+                cbz = (f0.z - st.r.oz) * st.qaz;
+    const float bnx = cbx - st.qmx, bny = cby - st.qmy, bnz = cbz - st.qmz;
+    const float bfx = cbx + st.qmx, bfy = cby + st.qmy, bfz = cbz + st.qmz;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float nx = __builtin_fmaf((float)((qnx >> (8 * k)) & 0xffu), cax, bnx);
+        const float ny = __builtin_fmaf((float)((qny >> (8 * k)) & 0xffu), cay, bny);
+        const float nz = __builtin_fmaf((float)((qnz >> (8 * k)) & 0xffu), caz, bnz);
+        const float fx = __builtin_fmaf((float)((qfx >> (8 * k)) & 0xffu), cax, bfx);
+        const float fy = __builtin_fmaf((float)((qfy >> (8 * k)) & 0xffu), cay, bfy);
+        const float fz = __builtin_fmaf((float)((qfz >> (8 * k)) & 0xffu), caz, bfz);
+        const float t1 = fminf(fminf(fx, fminf(fy, fz)), st.bound);
+        const float t0 = fmaxf(fmaxf(nx, fmaxf(ny, nz)), 0.0f);
+        const bool h = (t1 >= t0) && ref[k] != kNoChild;
+        key[k] = h ? fminf(t0, 3.0e38f) : INFINITY;
+        nh += h ? 1 : 0;
+    }
+#else
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float pnx = __builtin_fmaf((float)((qnx >> (8 * k)) & 0xffu), f0.w, f0.x);
+        const float pny = __builtin_fmaf((float)((qny >> (8 * k)) & 0xffu), f1.x, f0.y);
+        const float pnz = __builtin_fmaf((float)((qnz >> (8 * k)) & 0xffu), f1.y, f0.z);
+        const float pfx = __builtin_fmaf((float)((qfx >> (8 * k)) & 0xffu), f0.w, f0.x);
+        const float pfy = __builtin_fmaf((float)((qfy >> (8 * k)) & 0xffu), f1.x, f0.y);
+        const float pfz = __builtin_fmaf((float)((qfz >> (8 * k)) & 0xffu), f1.y, f0.z);
+        const float nx = (pnx - st.r.ox) * st.r.ix, fx = (pfx - st.r.ox) * st.r.ix;
+        const float ny = (pny - st.r.oy) * st.r.iy, fy = (pfy - st.r.oy) * st.r.iy;
+        const float nz = (pnz - st.r.oz) * st.r.iz, fz = (pfz - st.r.oz) * st.r.iz;
+        const float t1 = fminf(fminf(fx, fminf(fy, fz)), st.bound);
+        const float t0 = fmaxf(fmaxf(nx, fmaxf(ny, nz)), 0.0f);
+        const bool h = (t1 >= t0) && ref[k] != kNoChild;
+        key[k] = h ? fminf(t0, 3.0e38f) : INFINITY;
+        nh += h ? 1 : 0;
+    }
+#endif
+#ifdef PT_EXP_QUAD_EXTRA
+    // experiment: PT_EXP_QUAD_EXTRA more vector instructions per four-child step (what
+    // the launch pays -- or would save -- per instruction of this step)
+    {
+        float acc = key[0];
+#pragma unroll
+        for (int e = 0; e < PT_EXP_QUAD_EXTRA; ++e)
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(f0.x), "v"(f0.y));
+        if (acc == 12345.678f) key[0] = acc;
+    }
+#endif
+    // children in order of entry distance (misses last): five compare-exchanges.  (Singling
+    // out only the nearest child and pushing the others in child order saves a fifth of
+    // the step's instructions and was measured 3-5 % slower on the 28 M-triangle scenes:
+    // the order in which the pushed siblings are taken up matters.)
+#define PT_CE(a, b)                                                        \
+    {                                                                      \
+        const bool sw = key[b] < key[a];                                   \
+        const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];  \
+        const int32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];\
+        key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb;                \
+    }
+    PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#undef PT_CE
+    // No room for the farther children: as in the two-child step, the lane stops with
+    // the node itself on top of its stack.
+    const bool full = nh > 1 && st.sp + nh - 1 > stack_cap;
+    int32_t next = ref[0];
+    if (full) {
+        stack[st.sp * kTraceBlock] = st.cur;
+        ++st.sp;
+        next = kSentinel;
+    } else if (nh > 1) {
+        if (nh > 3) { stack[st.sp * kTraceBlock] = ref[3]; ++st.sp; }
+        if (nh > 2) { stack[st.sp * kTraceBlock] = ref[2]; ++st.sp; }
+        stack[st.sp * kTraceBlock] = ref[1];
+        ++st.sp;
+    } else if (nh == 0) {
+        --st.sp;
+        next = stack[st.sp * kTraceBlock];
+    }
+    st.cur = next;
+}
+
 // Advances the traversing lanes of the wave until at most `min_active` of them are still
 // traversing (0: run the wave's rays to completion).  Each round the wave votes on one step:
 // the lanes standing at a triangle take a triangle step once `leaf_lanes` of them have
@@ -567,108 +679,7 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                     f0 = np[0]; f1 = np[1]; f2 = np[2];
                     ch = reinterpret_cast<const int4 *>(np)[3];
                 }
-                if (COUNT) nb += 4;
-                const uint32_t qlx = __float_as_uint(f1.z), qly = __float_as_uint(f1.w),
-                               qlz = __float_as_uint(f2.x), qhx = __float_as_uint(f2.y),
-                               qhy = __float_as_uint(f2.z), qhz = __float_as_uint(f2.w);
-                float key[4];
-                int32_t ref[4] = {ch.x, ch.y, ch.z, ch.w};
-                int nh = 0;
-                // The slab test of bvh.glslh:165-177 on the decoded boxes, with the min / max of
-                // the two planes of an axis taken by the sign of 1/d instead (one select per axis
-                // for the four children together): the same numbers wherever no product is a NaN
-                // (a decoded lo is never above its hi, and rounding is monotonic), and where one is
-                // (a ray inside a box plane with no extent along that axis) the plane drops out
-                // of the max3 / min3 -- which can only let the ray into a coarse box the
-                // reference's arithmetic would have kept it out of.  Not so for a leaf's exact
-                // box, whose test is the reference's as written (triangle step).
-                const bool sgx = __float_as_int(st.r.ix) < 0, sgy = __float_as_int(st.r.iy) < 0,
-                           sgz = __float_as_int(st.r.iz) < 0;
-                const uint32_t qnx = sgx ? qhx : qlx, qfx = sgx ? qlx : qhx;
-                const uint32_t qny = sgy ? qhy : qly, qfy = sgy ? qly : qhy;
-                const uint32_t qnz = sgz ? qhz : qlz, qfz = sgz ? qlz : qhz;
-#ifndef PT_QUAD_REFERENCE_FORM
-                // see coarse_ray_terms
-                const float cax = f0.w * st.qax, cay = f1.x * st.qay, caz = f1.y * st.qaz;
-                const float cbx = (f0.x - st.r.ox) * st.qax, cby = (f0.y - st.r.oy) * st.qay,
-                            cbz = (f0.z - st.r.oz) * st.qaz;
-                const float bnx = cbx - st.qmx, bny = cby - st.qmy, bnz = cbz - st.qmz;
-                const float bfx = cbx + st.qmx, bfy = cby + st.qmy, bfz = cbz + st.qmz;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float nx = __builtin_fmaf((float)((qnx >> (8 * k)) & 0xffu), cax, bnx);
-                    const float ny = __builtin_fmaf((float)((qny >> (8 * k)) & 0xffu), cay, bny);
-                    const float nz = __builtin_fmaf((float)((qnz >> (8 * k)) & 0xffu), caz, bnz);
-                    const float fx = __builtin_fmaf((float)((qfx >> (8 * k)) & 0xffu), cax, bfx);
-                    const float fy = __builtin_fmaf((float)((qfy >> (8 * k)) & 0xffu), cay, bfy);
-                    const float fz = __builtin_fmaf((float)((qfz >> (8 * k)) & 0xffu), caz, bfz);
-                    const float t1 = fminf(fminf(fx, fminf(fy, fz)), st.bound);
-                    const float t0 = fmaxf(fmaxf(nx, fmaxf(ny, nz)), 0.0f);
-                    const bool h = (t1 >= t0) && ref[k] != kNoChild;
-                    key[k] = h ? fminf(t0, 3.0e38f) : INFINITY;
-                    nh += h ? 1 : 0;
-                }
-#else
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float pnx = __builtin_fmaf((float)((qnx >> (8 * k)) & 0xffu), f0.w, f0.x);
-                    const float pny = __builtin_fmaf((float)((qny >> (8 * k)) & 0xffu), f1.x, f0.y);
-                    const float pnz = __builtin_fmaf((float)((qnz >> (8 * k)) & 0xffu), f1.y, f0.z);
-                    const float pfx = __builtin_fmaf((float)((qfx >> (8 * k)) & 0xffu), f0.w, f0.x);
-                    const float pfy = __builtin_fmaf((float)((qfy >> (8 * k)) & 0xffu), f1.x, f0.y);
-                    const float pfz = __builtin_fmaf((float)((qfz >> (8 * k)) & 0xffu), f1.y, f0.z);
-                    const float nx = (pnx - st.r.ox) * st.r.ix, fx = (pfx - st.r.ox) * st.r.ix;
-                    const float ny = (pny - st.r.oy) * st.r.iy, fy = (pfy - st.r.oy) * st.r.iy;
-                    const float nz = (pnz - st.r.oz) * st.r.iz, fz = (pfz - st.r.oz) * st.r.iz;
-                    const float t1 = fminf(fminf(fx, fminf(fy, fz)), st.bound);
-                    const float t0 = fmaxf(fmaxf(nx, fmaxf(ny, nz)), 0.0f);
-                    const bool h = (t1 >= t0) && ref[k] != kNoChild;
-                    key[k] = h ? fminf(t0, 3.0e38f) : INFINITY;
-                    nh += h ? 1 : 0;
-                }
-#endif
-#ifdef PT_EXP_QUAD_EXTRA
-                // experiment: PT_EXP_QUAD_EXTRA more vector instructions per four-child step (what
-                // the launch pays -- or would save -- per instruction of this step)
-                {
-                    float acc = key[0];
-#pragma unroll
-                    for (int e = 0; e < PT_EXP_QUAD_EXTRA; ++e)
-                        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(f0.x), "v"(f0.y));
-                    if (acc == 12345.678f) key[0] = acc;
-                }
-#endif
-                // children in order of entry distance (misses last): five compare-exchanges.  (Singling
-                // out only the nearest child and pushing the others in child order saves a fifth of
-                // the step's instructions and was measured 3-5 % slower on the 28 M-triangle scenes:
-                // the order in which the pushed siblings are taken up matters.)
-#define PT_CE(a, b)                                                        \
-    {                                                                      \
-        const bool sw = key[b] < key[a];                                   \
-        const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];  \
-        const int32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];\
-        key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb;                \
-    }
-                PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
-#undef PT_CE
-                // No room for the farther children: as in the two-child step, the lane stops with
-                // the node itself on top of its stack.
-                const bool full = nh > 1 && st.sp + nh - 1 > stack_cap;
-                int32_t next = ref[0];
-                if (full) {
-                    stack[st.sp * kTraceBlock] = st.cur;
-                    ++st.sp;
-                    next = kSentinel;
-                } else if (nh > 1) {
-                    if (nh > 3) { stack[st.sp * kTraceBlock] = ref[3]; ++st.sp; }
-                    if (nh > 2) { stack[st.sp * kTraceBlock] = ref[2]; ++st.sp; }
-                    stack[st.sp * kTraceBlock] = ref[1];
-                    ++st.sp;
-                } else if (nh == 0) {
-                    --st.sp;
-                    next = stack[st.sp * kTraceBlock];
-                }
-                st.cur = next;
+                quad_node_step<COUNT>(st, stack, stack_cap, f0, f1, f2, ch, nb);
               }
             } else
             if (at_node) {
@@ -1382,6 +1393,7 @@ struct InstanceRay {
     float4 o, d;          // the ray in the instance's object space
     int32_t root;         // first two-child node of the instance's mesh
     uint32_t n_tri;
+    float cmax;           // largest coordinate of the mesh's boxes (see coarse_ray_terms)
 };
 __device__ __forceinline__ InstanceRay instance_ray(const DeviceScene &s, int32_t instance,
                                                     const float4 ro, const float4 rd) {
@@ -1392,6 +1404,7 @@ __device__ __forceinline__ InstanceRay instance_ray(const DeviceScene &s, int32_
     InstanceRay x;
     x.root = (int32_t)o0.y;
     x.n_tri = o1.y;
+    x.cmax = __uint_as_float(o1.w);
     x.o.x = ((r0.x * ro.x + r0.y * ro.y) + r0.z * ro.z) + r0.w;      // as enter_instance
     x.o.y = ((r1.x * ro.x + r1.y * ro.y) + r1.z * ro.z) + r1.w;
     x.o.z = ((r2.x * ro.x + r2.y * ro.y) + r2.z * ro.z) + r2.w;
@@ -1420,7 +1433,9 @@ __device__ __forceinline__ bool ray_is_ordinary(const float4 ro, const float4 rd
     return (fabsf(chk) < INFINITY) && (ro.w == ro.w) && !(rd.x == 0.f && rd.y == 0.f && rd.z == 0.f);
 }
 
-template <bool COUNT, bool ANY, bool BIG, class Sink, bool CACHE = false>
+// QUAD: inside the instances the four-child nodes are walked (DeviceScene::qnodes / qtris over
+// the meshes' records, built like a single-level scene's); the top-level tree stays two-child.
+template <bool COUNT, bool ANY, bool BIG, class Sink, bool CACHE = false, bool QUAD = false>
 __device__ __forceinline__ void persistent_traverse_two_level(
     const DeviceScene &s, const pt_ray *rays, uint32_t n, bool fixup, const PersistentParams pp,
     unsigned int *tie_count, DeviceTraceCounters *work, Sink sink) {
@@ -1537,7 +1552,12 @@ __device__ __forceinline__ void persistent_traverse_two_level(
             int mode = vote();
             // node steps in a loop of their own: only position and stack pointer change in it
             while (mode == 0) {
-                if (at_node) {
+                if (QUAD && at_node && cur_inst >= 0) {         // a four-child node of a mesh
+                    const float4 *np = quad_node<BIG>(s, st.cur);
+                    const float4 f0 = np[0], f1 = np[1], f2 = np[2];
+                    const int4 ch = reinterpret_cast<const int4 *>(np)[3];
+                    quad_node_step<COUNT>(st, stack, stack_cap, f0, f1, f2, ch, nb);
+                } else if (at_node) {
                     float4 a, b, c;
                     int2 ch;
                     if (CACHE && st.cur >= kLdsNodeBase) {      // a node of the top of the top level, in LDS
@@ -1591,27 +1611,40 @@ __device__ __forceinline__ void persistent_traverse_two_level(
                         ++st.sp;
                         cur_inst = inst;
                         set_space_ray<ANY>(st, x.o, x.d);
+                        if constexpr (QUAD) coarse_ray_terms(st, x.cmax);
                         st.cur = x.root;
                         // an object-space ray that is not finite, and (occlusion only) a mesh of a
                         // single triangle, whose filler record is safe under the watertight test
-                        // alone: left to the fixed order
-                        if (!ray_is_ordinary(x.o, x.d) || (ANY && x.n_tri < 2)) {
+                        // alone, or with four-child nodes a ray along an axis (see persistent_traverse):
+                        // left to the fixed order
+                        const bool axis_ray = QUAD && ANY &&
+                                              !(fabsf(st.r.ix) < INFINITY && fabsf(st.r.iy) < INFINITY &&
+                                                fabsf(st.r.iz) < INFINITY);
+                        if (!ray_is_ordinary(x.o, x.d) || (ANY && x.n_tri < 2) || axis_ray) {
                             st.tie = true;
                             st.cur = kSentinel;
                         }
                     }
                 }
             } else if (at_tri) {                                // triangle step, inside an instance
-                const float4 *tp = wide_tri<BIG>(s, st.cur);
+                const float4 *tp = QUAD ? quad_tri<BIG>(s, st.cur) : wide_tri<BIG>(s, st.cur);
                 const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                if (COUNT) ++nt;
+                bool in_leaf_box = true;
+                if constexpr (QUAD) {                           // the leaf's exact box (see ordered_advance)
+                    const float4 q3 = tp[3];
+                    float t;
+                    in_leaf_box = intersect_box(st.r, q2.z, q3.y, q2.w, q3.z, q3.x, q3.w, st.bound, t);
+                    if (COUNT) ++nb;
+                }
+                if (COUNT) nt += in_leaf_box ? 1 : 0;
                 if constexpr (ANY) {
                     float m1, m2, temp;
                     moller_trumbore(st.r.ox, st.r.oy, st.r.oz, st.r.sx, st.r.sy, st.r.sz, q0.x, q0.y,
                                     q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, m1, m2, temp);
                     const bool hit = !((m1 < -PT_MT_EPS) | (m1 > 1.f + PT_MT_EPS) | (m2 < -PT_MT_EPS) |
                                        (m1 + m2 > 1.f + PT_MT_EPS) | (temp < -PT_MT_EPS) |
-                                       (temp > st.tmax + PT_MT_EPS));           // bvh.glslh:301
+                                       (temp > st.tmax + PT_MT_EPS)) &          // bvh.glslh:301
+                                     in_leaf_box;
                     st.primid = hit ? 0 : st.primid;
                     --st.sp;
                     const int32_t popped = stack[st.sp * kTraceBlock];
@@ -1620,7 +1653,8 @@ __device__ __forceinline__ void persistent_traverse_two_level(
                     float h0 = 0.f, h1 = 0.f, h2 = 0.f, ht = 0.f;
                     const bool hit = intersect_triangle_watertight(st.r, q0.x, q0.y, q0.z, q0.w, q1.x,
                                                                    q1.y, q1.z, q1.w, q2.x, st.bound, h0,
-                                                                   h1, h2, ht);
+                                                                   h1, h2, ht) &
+                                     in_leaf_box;
                     const int32_t tri = __float_as_int(q2.y);
                     const bool bad = hit & !(ht == ht);
                     const bool had = st.primid >= 0;

@@ -124,12 +124,13 @@ __global__ __launch_bounds__(kBlock) void k_pt_extend_two_level(DeviceScene s, c
     }
 }
 
-template <bool COUNT, bool BIG, bool CACHE>
-__global__ __launch_bounds__(kBlock, PT_TWO_LEVEL_MIN_WAVES) void k_pt_extend_two_level_persistent(
+template <bool COUNT, bool BIG, bool CACHE, bool QUAD = false>
+__global__ __launch_bounds__(kBlock, QUAD ? PT_EXTEND_MIN_WAVES : PT_TWO_LEVEL_MIN_WAVES)
+void k_pt_extend_two_level_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, const unsigned int *count,
     unsigned int *tie_count, DeviceTraceCounters *work, PersistentParams pp) {
-    persistent_traverse_two_level<COUNT, false, BIG, HitSink, CACHE>(s, rays, *count, true, pp, tie_count, work,
-                                                                    HitSink{hits});
+    persistent_traverse_two_level<COUNT, false, BIG, HitSink, CACHE, QUAD>(s, rays, *count, true, pp, tie_count,
+                                                                          work, HitSink{hits});
 }
 
 // extend, persistent form: the grid is sized to the machine, not to the queue.  Queue
@@ -275,11 +276,11 @@ __global__ __launch_bounds__(kBlock) void k_pt_occlude_two_level(DeviceScene s, 
     ShadowSink{ws.shadow_carry, ws.radiance}((uint32_t)i, occ);
 }
 
-template <bool BIG, bool CACHE>
+template <bool BIG, bool CACHE, bool QUAD = false>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_pt_occlude_two_level_persistent(
     DeviceScene s, RenderWorkspace ws, const unsigned int *count, PersistentParams pp) {
-    persistent_traverse_two_level<false, true, BIG, ShadowSink, CACHE>(s, ws.shadow_rays, *count, true, pp, nullptr,
-                                                                      nullptr, ShadowSink{ws.shadow_carry, ws.radiance});
+    persistent_traverse_two_level<false, true, BIG, ShadowSink, CACHE, QUAD>(
+        s, ws.shadow_rays, *count, true, pp, nullptr, nullptr, ShadowSink{ws.shadow_carry, ws.radiance});
 }
 
 // Persistent waves with lane refill and step voting, as the closest-hit kernel.
@@ -364,9 +365,14 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
             k_pt_extend_two_level_persistent<false, true, false>,  k_pt_extend_two_level_persistent<false, true, true>,
             k_pt_extend_two_level_persistent<true, false, false>,  k_pt_extend_two_level_persistent<true, false, true>,
             k_pt_extend_two_level_persistent<true, true, false>,   k_pt_extend_two_level_persistent<true, true, true>};
-        launch_persistent(table[(work ? 4 : 0) | (s.big ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)], st,
-                          blocks(max_rays, kBlock), cfg, pp, s, (const pt_ray *)ws.rays[buf], ws.hits, count,
-                          tie_count, work, pp);
+        static const K quad_table[4] = {
+            k_pt_extend_two_level_persistent<false, false, false, true>, k_pt_extend_two_level_persistent<false, true, false, true>,
+            k_pt_extend_two_level_persistent<true, false, false, true>,  k_pt_extend_two_level_persistent<true, true, false, true>};
+        const K kernel = cfg.quad && s.qnodes
+                             ? quad_table[(work ? 2 : 0) | (s.big ? 1 : 0)]
+                             : table[(work ? 4 : 0) | (s.big ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)];
+        launch_persistent(kernel, st, blocks(max_rays, kBlock), cfg, pp, s, (const pt_ray *)ws.rays[buf], ws.hits,
+                          count, tie_count, work, pp);
         return;
     }
     if (s.tlas) {
@@ -426,8 +432,11 @@ void launch_pt_occlude(hipStream_t st, const DeviceScene &s, const RenderWorkspa
         static const K table[4] = {
             k_pt_occlude_two_level_persistent<false, false>, k_pt_occlude_two_level_persistent<false, true>,
             k_pt_occlude_two_level_persistent<true, false>,  k_pt_occlude_two_level_persistent<true, true>};
-        launch_persistent(table[(s.big ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)], st, blocks(max_rays, kBlock), cfg, pp,
-                          s, ws, shadow_count, pp);
+        static const K quad_table[2] = {k_pt_occlude_two_level_persistent<false, false, true>,
+                                        k_pt_occlude_two_level_persistent<true, false, true>};
+        const K kernel = cfg.quad && s.qnodes ? quad_table[s.big ? 1 : 0]
+                                              : table[(s.big ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)];
+        launch_persistent(kernel, st, blocks(max_rays, kBlock), cfg, pp, s, ws, shadow_count, pp);
         return;
     }
     if (s.tlas) {

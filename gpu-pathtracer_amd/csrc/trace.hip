@@ -149,18 +149,22 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_two_level(DeviceScene s, c
 }
 
 // Two-level scenes by persistent waves (see persistent_traverse_two_level).
-template <bool COUNT, bool BIG, bool CACHE>
-__global__ __launch_bounds__(kBlock, PT_TWO_LEVEL_MIN_WAVES) void k_trace_two_level_persistent(
+// (QUAD: four-child nodes inside the instances; those kernels keep no LDS copy of the top and,
+// like the single-level four-child kernels, are not held to five waves per SIMD.)
+template <bool COUNT, bool BIG, bool CACHE, bool QUAD = false>
+__global__ __launch_bounds__(kBlock, QUAD ? PT_EXTEND_MIN_WAVES : PT_TWO_LEVEL_MIN_WAVES)
+void k_trace_two_level_persistent(
     DeviceScene s, const pt_ray *rays, pt_hit *hits, uint32_t n, bool fixup, PersistentParams pp,
     DeviceTraceCounters *counters) {
-    persistent_traverse_two_level<COUNT, false, BIG, HitSink, CACHE>(s, rays, n, fixup, pp, &counters->tie_count,
-                                                                    counters, HitSink{hits});
+    persistent_traverse_two_level<COUNT, false, BIG, HitSink, CACHE, QUAD>(s, rays, n, fixup, pp,
+                                                                          &counters->tie_count, counters,
+                                                                          HitSink{hits});
 }
-template <bool BIG, bool CACHE>
+template <bool BIG, bool CACHE, bool QUAD = false>
 __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_two_level_persistent(
     DeviceScene s, const pt_ray *rays, int32_t *occluded, uint32_t n, PersistentParams pp) {
-    persistent_traverse_two_level<false, true, BIG, OccludedSink, CACHE>(s, rays, n, true, pp, nullptr, nullptr,
-                                                                        OccludedSink{occluded});
+    persistent_traverse_two_level<false, true, BIG, OccludedSink, CACHE, QUAD>(s, rays, n, true, pp, nullptr,
+                                                                              nullptr, OccludedSink{occluded});
 }
 
 // Sort key of a ray: 30-bit Morton code of its origin's cell in a 1024^3 grid over the scene's
@@ -523,8 +527,13 @@ void launch_trace_two_level(hipStream_t st, const DeviceScene &s, const pt_ray *
             k_trace_two_level_persistent<false, true, false>,  k_trace_two_level_persistent<false, true, true>,
             k_trace_two_level_persistent<true, false, false>,  k_trace_two_level_persistent<true, false, true>,
             k_trace_two_level_persistent<true, true, false>,   k_trace_two_level_persistent<true, true, true>};
-        launch_persistent(table[(count_work ? 4 : 0) | (s.big ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)], st, grid_for(n),
-                          cfg, pp, s, rays, hits, (uint32_t)n, fixup, pp, counters);
+        static const K quad_table[4] = {
+            k_trace_two_level_persistent<false, false, false, true>, k_trace_two_level_persistent<false, true, false, true>,
+            k_trace_two_level_persistent<true, false, false, true>,  k_trace_two_level_persistent<true, true, false, true>};
+        const K kernel = cfg.quad && s.qnodes
+                             ? quad_table[(count_work ? 2 : 0) | (s.big ? 1 : 0)]
+                             : table[(count_work ? 4 : 0) | (s.big ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)];
+        launch_persistent(kernel, st, grid_for(n), cfg, pp, s, rays, hits, (uint32_t)n, fixup, pp, counters);
         return;
     }
     if (count_work)
@@ -613,8 +622,11 @@ void launch_trace_any(hipStream_t st, const DeviceScene &s, const pt_ray *rays, 
             static const K table[4] = {
                 k_trace_any_two_level_persistent<false, false>, k_trace_any_two_level_persistent<false, true>,
                 k_trace_any_two_level_persistent<true, false>,  k_trace_any_two_level_persistent<true, true>};
-            launch_persistent(table[(s.big ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)], st, grid_for(n), cfg, pp, s, rays,
-                              occluded, (uint32_t)n, pp);
+            static const K quad_table[2] = {k_trace_any_two_level_persistent<false, false, true>,
+                                            k_trace_any_two_level_persistent<true, false, true>};
+            const K kernel = cfg.quad && s.qnodes ? quad_table[s.big ? 1 : 0]
+                                                  : table[(s.big ? 2 : 0) | (pp.cache_nodes > 0 ? 1 : 0)];
+            launch_persistent(kernel, st, grid_for(n), cfg, pp, s, rays, occluded, (uint32_t)n, pp);
             return;
         }
         hipLaunchKernelGGL(k_trace_any_two_level, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays,

@@ -67,6 +67,25 @@ def test_closest_and_any_hits_are_bit_exact(mipt, oracle, gpu_ctx, builder):
             np.testing.assert_array_equal(scene.trace_any(rays), t.any_hit(rays, nthreads=8))
         finally:
             gpu_ctx.set_option("extend.persistent", 1)
+        # the meshes' trees as four-child nodes with quantised boxes (what scenes whose meshes lie
+        # beyond the caches are walked by): every record the same again, also with few stack entries
+        # (a four-child step pushes up to three) and through the rays along the axes
+        for entries in (-1, 12):
+            gpu_ctx.set_option("extend.quad", 1)
+            gpu_ctx.set_option("extend.stack_entries", entries)
+            try:
+                quad, stq = scene.trace_closest(rays, stats=True)
+                assert same_hits(quad, want, nan_equal=True).size == 0
+                assert 0 < stq.box_tests and stq.tri_tests <= st.tri_tests
+                np.testing.assert_array_equal(scene.trace_any(rays), t.any_hit(rays, nthreads=8))
+                axis = rays[:20000].copy()
+                axis["d"][:, :3] = np.eye(3, dtype=np.float32)[np.arange(len(axis)) % 3] * \
+                    np.where(np.arange(len(axis)) % 2, -1.0, 1.0).astype(np.float32)[:, None]
+                assert same_hits(scene.trace_closest(axis), t.closest(axis, nthreads=8), nan_equal=True).size == 0
+                np.testing.assert_array_equal(scene.trace_any(axis), t.any_hit(axis, nthreads=8))
+            finally:
+                gpu_ctx.set_option("extend.quad", -1)
+                gpu_ctx.set_option("extend.stack_entries", -1)
         # a batch smaller than one wave, and an empty one
         assert same_hits(scene.trace_closest(rays[:37]), want[:37], nan_equal=True).size == 0
         assert scene.trace_closest(rays[:0]).shape[0] == 0
@@ -98,6 +117,15 @@ def test_render_matches_the_cpu_restatement(mipt, oracle, gpu_ctx, flags):
         n_diff = int((got.view(np.uint32) != want.view(np.uint32)).sum())
         assert n_diff == 0, f"film differs from the CPU restatement in {n_diff} words"
         assert got[..., :3].mean() > 0.01
+        # the same frame with the meshes walked as four-child nodes (closest hits and shadow rays)
+        gpu_ctx.set_option("extend.quad", 1)
+        try:
+            film.clear()
+            stq = mipt.render(gpu_ctx, scene, cam, p, film, stats=True)
+            assert int((film.read().view(np.uint32) != want.view(np.uint32)).sum()) == 0
+            assert stq.rays_primary + stq.rays_bounce + stq.rays_shadow == rays
+        finally:
+            gpu_ctx.set_option("extend.quad", -1)
         if flags:
             assert st.rays_shadow > 0
         # the reference's grey view of the same scene
@@ -167,6 +195,12 @@ def test_trees_built_by_the_library(mipt, oracle, gpu_ctx, encoding):
                                 sc["transforms"], sc["mesh_of"], top)
             assert same_hits(got, t.closest(rays, nthreads=8), nan_equal=True).size == 0
             np.testing.assert_array_equal(scene.trace_any(rays), t.any_hit(rays, nthreads=8))
+            gpu_ctx.set_option("extend.quad", 1)      # four-child nodes over trees with split leaves
+            try:
+                assert same_hits(scene.trace_closest(rays), got, nan_equal=True).size == 0
+                np.testing.assert_array_equal(scene.trace_any(rays), t.any_hit(rays, nthreads=8))
+            finally:
+                gpu_ctx.set_option("extend.quad", -1)
         # against the host-built trees: same instance and triangle except at ties
         other = ref_scene.trace_closest(rays)
         same = (got["shapeid"] == other["shapeid"]) & (got["primid"] == other["primid"])
