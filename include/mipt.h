@@ -217,10 +217,11 @@ int pt_context_last_trace_ms(pt_context *ctx, double *ms);
  * instead of through the vector memory pipeline (default -1: 16 entries + 224 nodes for trees
  * up to 40 levels deep that fit the 256 MB Infinity Cache, 24 + 96 for deeper or larger ones;
  * single-level scenes only);
- * "extend.quad" -1|0|1: closest hits walk the tree as 64-byte four-child nodes with 8-bit child
- * boxes and exact leaf boxes beside the triangles -- half the records per ray for more
- * arithmetic per record (default -1: trace calls on scenes beyond the Infinity Cache, render
- * passes on such scenes from the second bounce on); "scene.quad" 1|0: scenes created from now
+ * "extend.quad" -1|0|1: closest hits and occlusion queries walk the tree (of a two-level scene:
+ * the meshes' trees) as 64-byte four-child nodes with 8-bit child boxes and exact leaf boxes
+ * beside the triangles -- half the records per ray for more arithmetic per record (default -1:
+ * trace calls on scenes beyond the Infinity Cache, render passes on such scenes from the
+ * second bounce on); "scene.quad" 1|0: scenes created from now
  * on get that form built (64 bytes per node and per triangle; default 1);
  * "any.exact_order" 0|1: occlusion queries walk the reference's skip links
  * instead of the two-child nodes (default 0); "trace.sort_rays" -1|0|1: pt_trace_closest*
@@ -231,10 +232,15 @@ int pt_context_last_trace_ms(pt_context *ctx, double *ms);
  * SAH cost, a few times the build time; it changes the tree, not any hit).
  * "build.optimize_passes" 0..32 (default 0): passes of parallel insertion-based optimisation
  * over pt_scene_build's tree (and over the meshes pt_scene_create_instanced builds): every
- * node looks for the place where it would add the least surface area, and the moves that do
- * not touch each other's nodes are made.  About 1.5 ms per pass and million triangles; 16
- * passes bring the radix tree of a million-triangle scene from 75 % to 96 % of the host SAH
- * tree's closest-hit rate.  Deterministic.  "build.max_levels" 8..256 (default 256): an
+ * node looks for the place where it would cost the tree the least surface area, and the moves
+ * that do not touch each other's nodes are made; "build.treelet_every" 0..32 (default 3): after
+ * every so many of those passes one of treelet restructuring (the top of the subtree below
+ * every node rebuilt into its cheapest arrangement; 0: none).  About 1 ms per insertion pass
+ * and million triangles; six passes with the default treelet passes bring the radix tree to
+ * the host SAH tree's closest-hit rate (within 1 % either way on the scenes measured).
+ * Deterministic.  "build.split_ratio" 0..1000000 (default 4), "build.split_max" 1..256 (default
+ * 64), "build.split_budget" 0..1000 per cent (default 50): triangles that go into several
+ * leaves (see pt_scene_build).  "build.max_levels" 8..256 (default 256): an
  * optimised tree with more levels than this is given up for the plain radix tree, whose
  * depth the key length bounds (256 is what the level lists of the passes hold). */
 int pt_context_set_option(pt_context *ctx, const char *key, const char *value);
