@@ -149,6 +149,27 @@ def test_bench_renders_a_scene_file(tmp_path, kind):
     assert d["mean_radiance"] > 0
 
 
+def test_bench_on_a_tree_built_on_the_gpu(tmp_path):
+    """--bvh gpu: the scene comes from pt_scene_build instead of pt_bvh_build + pt_scene_create;
+    the line says so, and the CPU baseline walks the tree read back from the scene (the same
+    frame, so the same mean radiance up to the order of equal-distance hits)."""
+    common = ["--steps", "2", "--warmup", "1", "--tris", "65536", "--width", "320", "--height", "180",
+              "--spp-per-step", "4", "--no-hbm-record", "--cpu-baseline-scale", "4", "--no-live-counters"]
+    lines = {}
+    for bvh in ("host", "gpu"):
+        out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--bvh", bvh] + common,
+                             capture_output=True, text=True, timeout=280, cwd=str(tmp_path))
+        assert out.returncode == 0, out.stderr[-2000:]
+        got = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(got) == 1, out.stdout[-2000:]
+        lines[bvh] = json.loads(got[0])
+    g, h = lines["gpu"], lines["host"]
+    assert "GPU" in g["config"]["bvh_source"] and "GPU" not in h["config"]["bvh_source"]
+    assert g["value"] > 0 and g["cpu_baseline"]["value"] > 0
+    assert abs(g["mean_radiance"] - h["mean_radiance"]) <= 1e-3 * h["mean_radiance"]
+    assert abs(g["nodes_per_ray"] - h["nodes_per_ray"]) < 0.15 * h["nodes_per_ray"]
+
+
 def test_bench_measures_hbm_traffic_itself(tmp_path):
     """roofline.traffic of a default run is not copied from a file: the benchmark runs itself again
     under rocprofv3 --pmc (one counter per pass) and reports the bytes those passes counted."""
