@@ -79,3 +79,52 @@ def test_one_process_communicators(mipt, scenes, gpu_ctx):
     two = (C.c_void_p * 2)(gpu_ctx._h, gpu_ctx._h)
     out2 = (C.c_void_p * 2)()
     assert mipt.lib.pt_comm_create_all(two, 2, out2) == mipt.PT_ERR_INVALID      # two contexts on one GPU
+
+
+@pytest.mark.parametrize("world,root", [(2, 0), (3, 2), (5, 1), (8, 0), (8, 7)])
+def test_root_staging_layout_for_uneven_tile_counts(mipt, scenes, gpu_ctx, world, root):
+    """What the root of pt_film_gather_tiles does with the peers' slices, replayed on one GPU:
+    the slices (pt_film_packed_size pixels each, whole tiles; some ranks own fewer tiles than
+    others, some tiles are cut by the frame's edge) lie side by side in one staging buffer in rank order, the
+    root's own left out, and unpacking each from its offset assembles the frame bit for bit."""
+    import torch
+    sc, full = _film_with_content(mipt, scenes, gpu_ctx)        # 96 x 64
+    W, H, tile = 96, 64, 24                                     # 4 x 3 tiles, the last row cut
+    try:
+        ref = full.read()
+        slots = [full.packed_size(tile, k, world) for k in range(world)]
+        assert sum(slots) == 12 * tile * tile and all(n % (tile * tile) == 0 for n in slots)
+        assert (max(slots) > min(slots)) == (12 % world != 0)
+        # every rank's film holds its own tiles only
+        parts = []
+        for k in range(world):
+            part = mipt.Film(gpu_ctx, W, H)
+            if slots[k]:
+                buf = torch.empty((slots[k], 4), dtype=torch.float32, device="cuda")
+                gpu_ctx.synchronize()
+                full.pack_tiles(tile, k, world, buf.data_ptr())
+                part.unpack_tiles(tile, k, world, buf.data_ptr())
+                gpu_ctx.synchronize()
+            parts.append(part)
+        staging = torch.full((sum(slots) - slots[root], 4), float("nan"), dtype=torch.float32, device="cuda")
+        off = 0
+        for k in range(world):                                  # what the peers send, where the root receives it
+            if k == root or slots[k] == 0:
+                continue
+            gpu_ctx.synchronize()
+            parts[k].pack_tiles(tile, k, world, staging[off:].data_ptr())
+            off += slots[k]
+        assert off == staging.shape[0]
+        off = 0
+        for k in range(world):                                  # the root's unpacking loop
+            if k == root or slots[k] == 0:
+                continue
+            parts[root].unpack_tiles(tile, k, world, staging[off:].data_ptr())
+            off += slots[k]
+        gpu_ctx.synchronize()
+        np.testing.assert_array_equal(parts[root].read().view(np.uint32), ref.view(np.uint32))
+        for p in parts:
+            p.close()
+    finally:
+        full.close()
+        sc.close()
