@@ -71,6 +71,10 @@ def parse_args():
                     help="extra pt_bvh_options_set pairs for the host BVH build (e.g. mipt.optimize_passes=2)")
     ap.add_argument("--nee", action="store_true",
                     help="next-event estimation: one shadow ray per path vertex (counted in value)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="run the --gpus N ranks on GPU 0 all together, with gloo collectives staged through host "
+                         "memory: a rehearsal of the multi-rank control flow (sharding, single BVH build, "
+                         "barriers, frame assembly, the line) on a one-GPU box; its value is no measurement")
     ap.add_argument("--force-distributed", action="store_true",
                     help="with one rank: still bring up torch.distributed, the communicator and the frame "
                          "assembly as for several (rehearses the multi-GPU branches on a one-GPU box)")
@@ -154,7 +158,7 @@ def self_launch(args):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < (1 if args.rehearse_on_one_gpu else args.gpus):
         error_line(args, "--gpus %d but %d GPU%s visible" % (args.gpus, have, "" if have == 1 else "s"),
                    gpus_visible=have)
         return 2
@@ -211,6 +215,9 @@ def main():
     from mipt import scenes
     from mipt import distributed as D
 
+    rehearsal = args.rehearse_on_one_gpu
+    if rehearsal:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         if rank == 0:
             error_line(args, "rank %d has no GPU: %d visible" % (local_rank, torch.cuda.device_count()),
@@ -218,7 +225,9 @@ def main():
         return 2
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_distributed      # collectives and frame assembly in play
-    if multi:
+    if multi and rehearsal:
+        dist.init_process_group("gloo")
+    elif multi:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- host side: scene, BVH; then upload ------------------------------------------------
@@ -288,11 +297,34 @@ def main():
             else:
                 comm.reduce_film(film, root=0)
             ctx.synchronize()
+        elif args.sharding == "tiles" and rehearsal:
+            sizes = [film.packed_size(64, r, world) for r in range(world)]
+
+            def pack_host(r, buf):                  # through a device buffer: gloo moves host memory
+                tmp = torch.empty(buf.shape, dtype=torch.float32, device="cuda")
+                torch.cuda.current_stream().synchronize()
+                film.pack_tiles(64, r, world, tmp.data_ptr())
+                ctx.synchronize()
+                buf.copy_(tmp)
+
+            def unpack_host(r, buf):
+                tmp = buf.cuda()
+                torch.cuda.current_stream().synchronize()
+                film.unpack_tiles(64, r, world, tmp.data_ptr())
+                ctx.synchronize()
+
+            D.assemble_tiles(sizes, pack_host, unpack_host, "cpu")
         elif args.sharding == "tiles":
             sizes = [film.packed_size(64, r, world) for r in range(world)]
             D.assemble_tiles(sizes, lambda r, buf: film.pack_tiles(64, r, world, buf.data_ptr()),
                              lambda r, buf: film.unpack_tiles(64, r, world, buf.data_ptr()), "cuda",
                              sync=ctx.synchronize)
+        elif rehearsal:
+            ctx.synchronize()
+            host = film_t.cpu()
+            D.assemble_samples(host, dst=0)
+            film_t.copy_(host)
+            torch.cuda.synchronize()
         else:
             ctx.synchronize()
             D.assemble_samples(film_t, dst=0)
@@ -349,7 +381,8 @@ def main():
     elapsed = time.perf_counter() - t0
     extend_ms = kernel_ms["extend"]
 
-    agg = torch.tensor([elapsed, float(rays + shadow), float(paths)], dtype=torch.float64, device="cuda")
+    agg = torch.tensor([elapsed, float(rays + shadow), float(paths)], dtype=torch.float64,
+                       device="cpu" if rehearsal else "cuda")
     if multi:
         mx = agg.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -387,6 +420,7 @@ def main():
                        "bvh": ", ".join("%s=%s" % kv for kv in sorted(bvh_opts.items())),
                        "bvh_build_s": round(build_s, 3), "bvh_source": bvh_source,
                        "host_threads_per_rank": host_cores(),
+                       "rehearsal_on_one_gpu": bool(rehearsal),
                        "launched_by": os.environ.get("MIPT_BENCH_LAUNCHED_BY", "a launcher (WORLD_SIZE was set)"
                                                      if "WORLD_SIZE" in os.environ else "directly, one process"),
                        "sharding": "none (one GPU)" if world == 1 else

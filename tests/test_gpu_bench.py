@@ -149,6 +149,59 @@ def test_bench_renders_a_scene_file(tmp_path, kind):
     assert d["mean_radiance"] > 0
 
 
+@pytest.mark.parametrize("sharding,ranks", [("samples", 2), ("tiles", 3)])
+def test_bench_rehearses_several_ranks_on_one_gpu(tmp_path, sharding, ranks):
+    """--gpus N --rehearse-on-one-gpu: the N ranks the script starts itself all render on GPU 0 and
+    exchange over gloo -- the multi-rank control flow (one BVH build per node, shards per rank,
+    barriers, the frame assembled on rank 0, maxima over ranks, one line from rank 0) end to end
+    on the one GPU a test box has.  The assembled frame is the one-rank frame."""
+    common = ["--steps", "3", "--warmup", "1", "--tris", "65536", "--width", "320", "--height", "192",
+              "--spp-per-step", "6", "--no-hbm-record", "--no-cpu-baseline", "--no-live-counters"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + common, capture_output=True,
+                         text=True, timeout=280, cwd=str(tmp_path), env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(ranks),
+                          "--rehearse-on-one-gpu", "--assembly", "torch", "--sharding", sharding] + common,
+                         capture_output=True, text=True, timeout=280, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["config"]["rehearsal_on_one_gpu"] is True
+    assert "bench.py itself" in d["config"]["launched_by"] and d["config"]["assembly"].startswith("torch")
+    assert d["scaling"] == "strong" and d["value"] > 0
+    # the same frame: every sample of every step reached rank 0's film
+    assert abs(d["config"]["samples_per_pixel_total"] - ref["config"]["samples_per_pixel_total"]) < 1e-6
+    assert abs(d["mean_radiance"] - ref["mean_radiance"]) <= 1e-5 * ref["mean_radiance"]
+    assert "built by rank 0" in d["config"]["bvh_source"] or "rank" in d["config"]["bvh_source"]
+
+
+def test_bench_rehearsal_falls_back_when_the_communicator_cannot_come_up(tmp_path):
+    """Two ranks on one GPU asking for the library's own communicator: the 128-byte id travels from
+    rank 0 to rank 1 and both call ncclCommInitRank, which RCCL turns down (two ranks, one
+    device).  Both ranks must learn of it, agree, and assemble with torch.distributed instead;
+    the line says which way the frame went."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu",
+                          "--assembly", "abi", "--comm-timeout", "30", "--steps", "2", "--warmup", "1",
+                          "--tris", "65536", "--width", "320", "--height", "192", "--spp-per-step", "4",
+                          "--no-hbm-record", "--no-cpu-baseline", "--no-live-counters"],
+                         capture_output=True, text=True, timeout=280, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["assembly"].startswith("torch.distributed") and "did not come up" in d["config"]["assembly"]
+    assert abs(d["config"]["samples_per_pixel_total"] - 8.0) < 1e-6
+
+
 def test_bench_on_a_tree_built_on_the_gpu(tmp_path):
     """--bvh gpu: the scene comes from pt_scene_build instead of pt_bvh_build + pt_scene_create;
     the line says so, and the CPU baseline walks the tree read back from the scene (the same
