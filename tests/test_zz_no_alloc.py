@@ -106,7 +106,10 @@ def test_static_entry_point_under_graph_capture(mipt, oracle, scenes, gpu_ctx):
     stream = torch.cuda.Stream()
     try:
         gpu_ctx.set_stream(stream.cuda_stream)
-        for sc, rays, want in ((flat, flat_rays, flat_want), (two, two_rays, two_want)):
+        # each scene with its default walk and with the four-child nodes (other kernels)
+        for sc, rays, want, quad in ((flat, flat_rays, flat_want, -1), (two, two_rays, two_want, -1),
+                                     (flat, flat_rays, flat_want, 1), (two, two_rays, two_want, 1)):
+            gpu_ctx.set_option("extend.quad", quad)
             n = len(rays)
             d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8).copy()).cuda()
             d_h = torch.full_like(d_r, -7.0)
@@ -126,6 +129,7 @@ def test_static_entry_point_under_graph_capture(mipt, oracle, scenes, gpu_ctx):
             del graph
     finally:
         gpu_ctx.synchronize()
+        gpu_ctx.set_option("extend.quad", -1)
         gpu_ctx.set_stream(None)                       # back to the context's own stream
         flat.close()
         two.close()
