@@ -14,7 +14,8 @@ for a in sys.argv[1:]:
     if "=" in a:
         k_, _, v_ = a.partition("=")
         ctx.set_option(k_, int(v_))
-vtx, idx, _, _ = scenes.displaced_sphere(int(os.environ.get("TRIS", "28000000")), seed=7)
+gen = scenes.displaced_cube_sphere if os.environ.get("SCENE", "uv") == "cube" else scenes.displaced_sphere
+vtx, idx, _, _ = gen(int(os.environ.get("TRIS", "28000000")), seed=7)
 ctx.set_option("build.optimize_passes", 8)
 sc = mipt.Scene(ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
 N = 1 << int(os.environ.get('LGN', '16'))
@@ -30,19 +31,20 @@ def ms(lo, n):
     sc.trace_closest_device(p, n, d_h.data_ptr())
     return ctx.last_trace_ms()
 
-slow = []
-for lo in range(0, N, 1024):
-    t = ms(lo, 1024)
-    if t > 1.0:
-        slow.append((lo, t))
+times = [(ms(lo, 1024), lo) for lo in range(0, N, 1024)]
+med = float(np.median([t for t, _ in times]))
+THRESH = float(os.environ.get("THRESH", "0")) or 2.0 * med      # ms: what counts as slow
+print(json.dumps({"ranges_of_1024": len(times), "median_ms": round(med, 4),
+                  "max_ms": round(max(times)[0], 4), "threshold_ms": round(THRESH, 4)}), flush=True)
+slow = sorted([(lo, t) for t, lo in times if t > THRESH], key=lambda x: -x[1])
 print("slow 1024-ray ranges:", slow[:20], flush=True)
 found = []
 for lo, _ in slow[:6]:
     for l2 in range(lo, lo + 1024, 64):
-        if ms(l2, 64) > 1.0:
+        if ms(l2, 64) > THRESH:
             for r in range(l2, l2 + 64):
                 t = ms(r, 1)
-                if t > 1.0:
+                if t > THRESH:
                     st = sc.trace_closest_device_counted(d_r.data_ptr() + 32 * r, 1, d_h.data_ptr())
                     hit = d_h[0].cpu().numpy()
                     found.append(r)
