@@ -264,7 +264,7 @@ def main():
     if nodes is None:
         ctx.synchronize()
         build_s = time.time() - t0
-        ctx.set_option("build.optimize_passes", 0)
+        ctx.set_option("build.optimize_passes", 6)
         nodes = scene.read_nodes()          # what the CPU legs walk
     W, H, spp = args.width, args.height, args.spp_per_step
     cam = make_camera(W / H)
@@ -628,7 +628,6 @@ def hbm_record(args, ctx, torch, mipt, scenes, kind=None, live=None):
     sc = mipt.Scene(ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
     ctx.synchronize()
     build_s = time.perf_counter() - t0
-    ctx.set_option("build.optimize_passes", 0)
     leaves = (int(mipt.lib.pt_scene_node_count(sc._h)) + 1) // 2
     d_r = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
     d_h = torch.empty_like(d_r)

@@ -50,7 +50,7 @@ struct pt_context {
     int sort_dir_bits = 0;          // option "trace.sort_dir_bits"
     int trace_sort_rays = -1;       // option "trace.sort_rays": 0 off, 1 on, -1 by scene size
     int build_ploc_radius = 0;      // option "build.ploc_radius": 0 = radix tree, else clustering
-    int build_optimize_passes = 0;  // option "build.optimize_passes": insertion-based optimisation rounds
+    int build_optimize_passes = 6;  // option "build.optimize_passes": insertion-based optimisation rounds
     int build_treelet_every = 3;    // option "build.treelet_every": a treelet round after so many of them (0: none)
     int build_max_levels = 256;     // option "build.max_levels"
     // Triangle splitting in the GPU builder (bvh.sah.use_splits of the reference's builder,

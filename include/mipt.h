@@ -230,7 +230,7 @@ int pt_context_last_trace_ms(pt_context *ctx, double *ms);
  * of them.  "build.ploc_radius" 0..64 selects pt_scene_build's tree: 0 (default) a binary radix
  * tree over the Morton codes, r > 0 locally-ordered clustering with search radius r (lower
  * SAH cost, a few times the build time; it changes the tree, not any hit).
- * "build.optimize_passes" 0..32 (default 0): passes of parallel insertion-based optimisation
+ * "build.optimize_passes" 0..32 (default 6): passes of parallel insertion-based optimisation
  * over pt_scene_build's tree (and over the meshes pt_scene_create_instanced builds): every
  * node looks for the place where it would cost the tree the least surface area, and the moves
  * that do not touch each other's nodes are made; "build.treelet_every" 0..32 (default 3): after

@@ -27,7 +27,7 @@ def algorithm(request, gpu_ctx):
     gpu_ctx.set_option("build.split_ratio", 0)           # one leaf per triangle: the tests with splits say so
     yield request.param
     gpu_ctx.set_option("build.ploc_radius", 0)
-    gpu_ctx.set_option("build.optimize_passes", 0)
+    gpu_ctx.set_option("build.optimize_passes", 6)
     gpu_ctx.set_option("build.treelet_every", 3)         # the library's defaults
     gpu_ctx.set_option("build.split_ratio", 4)
 
@@ -151,7 +151,7 @@ def test_optimisation_passes_improve_the_tree(mipt, scenes, gpu_ctx, algorithm):
             finally:
                 sc.close()
     finally:
-        gpu_ctx.set_option("build.optimize_passes", 0)
+        gpu_ctx.set_option("build.optimize_passes", 6)
     assert boxes[1] < boxes[0] and boxes[2] < 0.92 * boxes[0], boxes
     for h in hits[1:]:
         # the nearest distance does not depend on the tree; which of two triangles at one distance
@@ -189,7 +189,7 @@ def test_treelet_rounds_improve_the_tree(mipt, oracle, scenes, gpu_ctx, algorith
             finally:
                 sc.close()
     finally:
-        gpu_ctx.set_option("build.optimize_passes", 0)
+        gpu_ctx.set_option("build.optimize_passes", 6)
         gpu_ctx.set_option("build.treelet_every", 3)
     assert cost[1] < cost[4] < cost[0], cost
     assert boxes[1] < boxes[0] and boxes[4] < boxes[0], boxes
@@ -242,7 +242,7 @@ def test_too_deep_a_tree_falls_back_to_the_radix_tree(mipt, oracle, gpu_ctx, alg
                     sc.close()
     finally:
         gpu_ctx.set_option("build.ploc_radius", 0)
-        gpu_ctx.set_option("build.optimize_passes", 0)
+        gpu_ctx.set_option("build.optimize_passes", 6)
         gpu_ctx.set_option("build.max_levels", 256)
     radix = levels[256, 0, 0]
     assert radix <= 36 and levels[36, 0, 0] == radix

@@ -193,7 +193,7 @@ def test_millions_of_rays_with_ties_and_deep_trees_match_the_oracle(mipt, oracle
     try:
         sc = mipt.Scene(gpu_ctx, None, vtx, idx, link_encoding=mipt.PT_LINKS_INT_BITS)
     finally:
-        gpu_ctx.set_option("build.optimize_passes", 0)
+        gpu_ctx.set_option("build.optimize_passes", 6)
     try:
         nodes = sc.read_nodes()
         got = sc.trace_closest(rays)
