@@ -688,7 +688,8 @@ __global__ __launch_bounds__(kB) void k_u_parents(UTree u) {
     u.parent[u.t.right[id]] = (int32_t)id;
 }
 
-// depth of every node (root 0), the identity list to sort by it, and the level histogram;
+// depth of every node (root 0); for the inner nodes the identity list to sort by it and the level
+// histogram (the level lists hold inner nodes only: no per-level kernel has work at a leaf);
 // flag[0] is set if a node lies deeper than the level lists reach
 __global__ __launch_bounds__(kB) void k_u_depth(UTree u, uint32_t *depth, uint32_t *ids,
                                                 unsigned int *histogram, unsigned int *flag) {
@@ -704,8 +705,10 @@ __global__ __launch_bounds__(kB) void k_u_depth(UTree u, uint32_t *depth, uint32
             d = kUMaxDepth - 1;
         }
         depth[id] = d;
-        ids[id] = id;
-        atomicAdd(&s_hist[d], 1u);
+        if (id >= u.n) {
+            ids[id] = id;
+            atomicAdd(&s_hist[d], 1u);
+        }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < kUMaxDepth; k += kB)
@@ -1219,8 +1222,8 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
             hipError_t e = hipMemsetAsync(uhist, 0, 4 * (kUMaxDepth + 8), st);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k_u_depth, dim3(g_all), dim3(kB), 0, st, u, udepth, uids, uhist, uflags);
-            e = hipcub::DeviceRadixSort::SortPairs(base + o_usort, usort_bytes, udepth, udepth2, uids, uids2,
-                                                   (int)total_nodes, 0, 8, st);
+            e = hipcub::DeviceRadixSort::SortPairs(base + o_usort, usort_bytes, udepth + n, udepth2, uids + n,
+                                                   uids2, (int)n_inner, 0, 8, st);
             if (e != hipSuccess) return e;
             unsigned int h[kUMaxDepth + 8];
             e = hipMemcpyAsync(h, uhist, sizeof(h), hipMemcpyDeviceToHost, st);
@@ -1232,7 +1235,7 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
                 begin[d + 1] = begin[d] + h[d];
                 if (h[d]) deepest = d;
             }
-            if (deepest >= max_levels) return hipErrorInvalidValue;
+            if (deepest + 1 >= max_levels) return hipErrorInvalidValue;     // the leaves lie one level further down
             for (int d = deepest; d >= 0; --d) {
                 const uint32_t cnt = begin[d + 1] - begin[d];
                 if (cnt)
@@ -1297,7 +1300,7 @@ DeviceBuildResult build_once(hipStream_t st, const float *d_vtx, const int32_t *
         hipLaunchKernelGGL(k_ploc_emit, dim3(g_all), dim3(kB), 0, st, ea);
         BUILD_CHECK(hipGetLastError());
         BUILD_CHECK(hipStreamSynchronize(st));
-        res.max_depth = (uint32_t)deepest + 1;
+        res.max_depth = (uint32_t)deepest + 2;
         return res;
     };
     PlocNodes unified_nodes{};
