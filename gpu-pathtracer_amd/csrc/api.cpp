@@ -111,6 +111,8 @@ ExtendConfig make_extend_config(const pt_context *ctx, const pt_scene *scene, bo
     c.max_grid = 0;
     c.xcd_slots = ctx->extend_xcd_slots > 0 ? 1 : 0;
     c.quad = 0;
+    c.long_list = ctx->long_list;
+    c.tail_budget = ctx->extend_tail_budget;
     // The LDS of a persistent workgroup (measured on MI355X: 262 K-triangle scene in the caches;
     // 10 M- and 28 M-triangle scenes beyond them, host-built trees of 32-36 levels and GPU-built
     // ones of 50-70):
@@ -383,6 +385,11 @@ int pt_context_create(int device, pt_context **out) {
     ctx->stream = ctx->own_stream;
     HIP_CHECK(hipMalloc((void **)&ctx->counters, sizeof(DeviceTraceCounters)));
     HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(DeviceTraceCounters), ctx->stream));
+    {   // the list of rays a closest-hit launch hands to its wave-per-ray kernel (256 KB)
+        const size_t bytes = sizeof(uint32_t) * (kLongListHeader + (size_t)kLongListCap);
+        HIP_CHECK(hipMalloc((void **)&ctx->long_list, bytes));
+        HIP_CHECK(hipMemsetAsync(ctx->long_list, 0, bytes, ctx->stream));
+    }
     // (the global stack slots of rays that outgrow the LDS stack come with the first scene whose
     // tree is deep enough to need them: ensure_stack_spill)
     // this device's address of the static scratch array of pt_trace_closest_device_static
@@ -441,6 +448,9 @@ int pt_context_set_option(pt_context *ctx, const char *key, const char *value) {
     } else if (k == "extend.leaf_lanes") {
         if (v < 1 || v > 64) return fail(PT_ERR_INVALID, "extend.leaf_lanes must be in [1,64]");
         ctx->extend_leaf_lanes = (int)v;
+    } else if (k == "extend.tail_budget") {
+        if (v < 0 || v > 1000000) return fail(PT_ERR_INVALID, "extend.tail_budget must be in [0,1000000]");
+        ctx->extend_tail_budget = (int)v;
     } else if (k == "build.ploc_radius") {
         if (v < 0 || v > 64) return fail(PT_ERR_INVALID, "build.ploc_radius must be in [0,64]");
         ctx->build_ploc_radius = (int)v;
@@ -1061,6 +1071,7 @@ static int trace_closest_impl(pt_context *ctx, const pt_scene *scene, const pt_r
         stats->tri_tests = c.tri_tests;
         stats->tie_rays = c.tie_count;
         stats->lds_box_tests = c.lds_box_tests;
+        stats->long_rays = c.long_rays;
     }
     return PT_OK;
 }

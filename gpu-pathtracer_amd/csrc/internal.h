@@ -40,6 +40,7 @@ struct pt_context {
     int extend_refill = 24;         // option "extend.refill"
     int extend_leaf_lanes = 16;     // option "extend.leaf_lanes"
     int extend_blocks_per_cu = -1;  // option "extend.blocks_per_cu" (-1: chosen per scene, 5 or 4)
+    int extend_tail_budget = 64;    // option "extend.tail_budget": rounds a wave may spend on its last rays (0: all it takes)
     int extend_stack_entries = -1;  // option "extend.stack_entries" (-1: chosen per scene)
     int extend_cache_nodes = -1;    // option "extend.cache_nodes" (-1: chosen per scene)
     int any_exact_order = 0;        // option "any.exact_order"
@@ -68,6 +69,7 @@ struct pt_context {
     mipt::DeviceBuffer sort_scratch;    // keys and order of a sorted trace call
     mipt::DeviceBuffer render_counts;   // queue sizes per pass and bounce
     mipt::DeviceBuffer stack_spill;     // see ExtendConfig::spill and ensure_stack_spill
+    uint32_t *long_list = nullptr;      // see PersistentParams::long_list (allocated with the context)
     std::vector<hipEvent_t> events;     // pool for per-kernel timing
     hipEvent_t trace_events[2] = {nullptr, nullptr};   // around the last trace call's kernel
     bool trace_timed = false;
@@ -88,6 +90,8 @@ struct pt_context {
         stack_spill.release();
         if (counters) (void)hipFree(counters);
         counters = nullptr;
+        if (long_list) (void)hipFree(long_list);
+        long_list = nullptr;
         if (own_stream) (void)hipStreamDestroy(own_stream);
         own_stream = nullptr;
     }

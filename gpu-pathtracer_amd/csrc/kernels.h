@@ -145,14 +145,24 @@ struct PersistentParams {
     int stack_cap;      // per-lane LDS stack entries (without the bottom sentinel)
     int cache_nodes;    // nodes of the scene's top_cache a workgroup keeps in LDS
     int xcd_slots;      // deal every round's chunks to the XCDs in contiguous eighths
+    // Rays a wave still holds tail_budget rounds after its stream has ended go to this list
+    // (closest hits by the four-child kernels on single-level scenes; null or 0: every wave
+    // finishes its own rays):
+    // long_list[0] entries appended, [1] waves of the second kernel that are done, then from
+    // kLongListHeader on up to long_cap ray indices.
+    uint32_t *long_list;
+    uint32_t long_cap;
+    int tail_budget;
 };
+constexpr uint32_t kLongListHeader = 4;
+constexpr uint32_t kLongListCap = 1u << 16;
 
 // Device counters of a trace call (mirrors pt_trace_stats, device side).
 struct DeviceTraceCounters {
     unsigned long long box_tests;
     unsigned long long tri_tests;
     unsigned int tie_count;   // entries appended to the tie list
-    unsigned int _pad;
+    unsigned int long_rays;   // rays handed to the wave-per-ray search (see PersistentParams::long_list)
     unsigned long long lds_box_tests;   // of box_tests: on nodes read from the LDS copy of the top of the tree
 };
 
@@ -180,6 +190,9 @@ struct ExtendConfig {
     // persistent form: upper bound on the grid in workgroups (0: none), for a spill area that
     // was sized for fewer lanes than the device could keep resident
     unsigned int max_grid;
+    // persistent closest-hit form, single-level scenes: see PersistentParams::long_list
+    uint32_t *long_list;
+    int tail_budget;
 };
 
 // Stack entries per lane beyond the LDS ones: a ray stays in the voted loop up to about
@@ -235,7 +248,10 @@ inline unsigned int persistent_lds_bytes(const PersistentParams &pp) {
 // The loop parameters of a launch on scene s: the cache never holds more nodes than the scene
 // has prepared (of a two-level scene: nodes of the top-level tree).
 inline PersistentParams persistent_params(const ExtendConfig &cfg, const DeviceScene &s) {
-    PersistentParams pp;
+    PersistentParams pp{};
+    pp.long_list = (s.tlas || !(cfg.quad && s.qnodes)) ? nullptr : cfg.long_list;   // four-child kernels only
+    pp.long_cap = kLongListCap;
+    pp.tail_budget = cfg.tail_budget;
     pp.refill = cfg.refill;
     pp.leaf_lanes = cfg.leaf_lanes;
     pp.spill = cfg.spill;
@@ -258,6 +274,13 @@ inline void launch_persistent(void (*kernel)(KArgs...), hipStream_t st, uint64_t
         n_blocks_wanted, persistent_grid((const void *)kernel, PT_TRACE_BLOCK, cfg, lds));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(PT_TRACE_BLOCK), lds, st, args...);
 }
+
+// The second kernel of a persistent closest-hit launch that hands its long rays over
+// (PersistentParams::long_list): one wave per listed ray.  Launch it on the same stream right
+// after the traversal kernel, with the same rays and hits; it empties the list.  No-op when
+// pp.long_list is null.  work may be null.
+void launch_long_rays(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits, bool fixup,
+                      const PersistentParams &pp, unsigned int *tie_count, DeviceTraceCounters *work);
 
 // Occlusion query.  exact_order: walk the skip links as the reference does; otherwise the
 // two-child nodes, nearer child first (the answer is the same).

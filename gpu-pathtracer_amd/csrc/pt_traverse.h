@@ -648,8 +648,15 @@ __device__ __forceinline__ void ordered_advance(const DeviceScene &s, OrderedSta
                                                 unsigned long long &nb, unsigned long long &nt,
                                                 int stack_cap = kTraceStack,
                                                 const LdsFloat4 *cache = nullptr,
-                                                unsigned long long *nl = nullptr) {
+                                                unsigned long long *nl = nullptr,
+                                                int *budget = nullptr) {
     for (;;) {
+        // budget (wave-uniform, optional): rounds of this loop -- a run of node steps and the
+        // triangle step after it -- the wave may still make; see the tail of persistent_traverse
+        if (budget) {
+            if (*budget <= 0) return;
+            --*budget;
+        }
         // Node steps run in a loop of their own: only the position and the stack pointer
         // change in it, so the rest of the lane's state stays put in its registers.
         // The vote: 0 node step, 1 triangle step, 2 done (the same value in every lane).
@@ -1211,6 +1218,18 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
     unsigned int n_ties = 0;
     const bool any_exact = s.n_tri < 2;         // see occluded_wide
     int spilled = 0;                            // blocks of this lane's stack in global memory
+    // Once a wave's stream has ended, its remaining rays are normally done within a few rounds.
+    // A ray that is not (one that runs along a fan of slivers makes thousands of steps, one after
+    // the other in its lane) would hold the whole launch: after tail_budget more rounds the wave
+    // hands what it still has to the list of long rays, which a second kernel searches with a
+    // whole wave per ray (long_ray_search), and ends.
+    int tail_left = pp.tail_budget;
+    // (Compiled into the four-child kernels only, the ones scenes beyond the caches get: there a
+    // step is a trip to memory and such a ray costs milliseconds; the cache-resident kernel,
+    // where it would cost a fraction of that, loses 1.5 % of its rate with the hand-over and the
+    // second launch in place, and stays as it was.)
+    constexpr bool hand_over_allowed = QUAD && !ANY;
+    bool hand_over = hand_over_allowed && pp.long_list != nullptr && pp.tail_budget > 0;
     // A ray whose answer may depend on the visiting order is walked again in the reference's
     // fixed order.  That walk is serial and long, so a lane does not start it on the spot with
     // the other 63 waiting: it parks the ray here and goes on, and the parked rays of a wave
@@ -1352,8 +1371,24 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
             if (pos >= stream_len) break;
             continue;                                           // tail positions past the queue end
         }
-        ordered_advance<COUNT, ANY, CACHE, BIG, QUAD>(s, st, stack, pos < stream_len ? 64 - refill : 0,
-                                                leaf_lanes, nb, nt, stack_cap, cache, &nl);
+        const bool tail = pos >= stream_len;
+        if (hand_over && tail && tail_left <= 0) {
+            hand_over = false;                                  // one attempt: a full list leaves the rest here
+            if (my_ray != kNone) {
+                const uint32_t at = atomicAdd(&pp.long_list[0], 1u);
+                if (at < pp.long_cap) {
+                    pp.long_list[kLongListHeader + at] = my_ray;
+                    my_ray = kNone;
+                    st.cur = kSentinel;
+                    spilled = 0;
+                }
+            }
+            continue;
+        }
+        int rounds = hand_over && tail ? tail_left : INT_MAX;   // (a plain local: stays in a register)
+        ordered_advance<COUNT, ANY, CACHE, BIG, QUAD>(s, st, stack, tail ? 0 : 64 - refill, leaf_lanes, nb, nt,
+                                                stack_cap, cache, &nl, hand_over_allowed ? &rounds : nullptr);
+        if (hand_over && tail) tail_left = rounds;
     }
     if constexpr (!ANY) walk_parked();
     if (!ANY && n_ties) atomicAdd(tie_count, n_ties);
@@ -1365,6 +1400,132 @@ __device__ __forceinline__ void persistent_traverse(const DeviceScene &s, const 
             atomicAdd(&work->box_tests, nb);
             atomicAdd(&work->tri_tests, nt);
             atomicAdd(&work->lds_box_tests, nl);
+        }
+    }
+}
+
+// ---- one wave per ray --------------------------------------------------------------------------
+// For the rays the persistent loop hands over (PersistentParams::long_list): the closest hit of
+// one ray searched by all 64 lanes of a wave.  The pending nodes and leaves sit on one stack in
+// LDS; each round the lanes take the top 64 entries, one each -- a node's two child boxes are
+// tested and the hit children pushed, a leaf's triangle is tested -- and the hits of the round
+// are merged into the nearest and the second nearest triangle seen so far.  Boxes and triangles
+// are culled with the nearest hit widened by the tie window, as in ordered_advance, so whatever
+// lies within the window of the final nearest hit is seen whatever the order, and the rules that
+// send a ray to the reference's fixed order are the same: a second triangle within the window,
+// a hit within the window of the ray's own reach, a value that is not finite; also a stack that
+// outgrows its LDS.  Such a ray gets traverse_skiplink as it is (by every lane alike: same
+// addresses, one answer).  The triangle tests are the same code on the same numbers as anywhere
+// else, so the record written is the one the persistent loop would have written.
+// The two-child nodes are walked, also where the persistent loop walked the four-child ones.
+constexpr int kLongStack = 2048;            // entries per wave
+__device__ __forceinline__ bool ray_is_ordinary(const float4 ro, const float4 rd);
+template <bool BIG, class Sink>
+__device__ __forceinline__ void long_ray_search(const DeviceScene &s, const pt_ray *rays, uint32_t ray,
+                                                int32_t *stk, bool fixup, unsigned int *tie_count,
+                                                DeviceTraceCounters *work, Sink sink) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const float4 ro = reinterpret_cast<const float4 *>(rays + ray)[0];
+    const float4 rd = reinterpret_cast<const float4 *>(rays + ray)[1];
+    int32_t shapeid = -1, primid = -1;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, t = ro.w;
+    unsigned long long nb = 0, nt = 0;
+    bool exact = !ray_is_ordinary(ro, rd) || s.n_tri < 2;
+    if (!exact) {
+        const RayPre r = precompute_ray(ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+        const float tmax = ro.w;
+        float t1 = tmax, t2 = INFINITY, c0 = 0.f, c1 = 0.f, c2 = 0.f;     // nearest, second nearest
+        int32_t p1 = -1, p2 = -1;
+        float bound = tmax + tmax * PT_TIE_WINDOW;
+        bool tie = false, overflow = false;
+        int top = 1;
+        if (lane == 0) stk[0] = 0;                                      // the root
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        while (top > 0) {
+            const int take = top < 64 ? top : 64;
+            const int32_t e = lane < take ? stk[top - 1 - lane] : kSentinel;
+            top -= take;
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            bool push_a = false, push_b = false, hit = false;
+            int32_t child_a = 0, child_b = 0, hp = -1;
+            float h0 = 0.f, h1 = 0.f, h2 = 0.f, ht = 0.f;
+            if (lane < take && e >= 0) {
+                const float4 *np = wide_node<BIG>(s, e);
+                const float4 a = np[0], b = np[1], c = np[2];
+                const int2 ch = reinterpret_cast<const int2 *>(np + 3)[0];
+                float ta, tb;
+                push_a = intersect_box(r, a.x, a.y, a.z, a.w, c.x, c.y, bound, ta);
+                push_b = intersect_box(r, b.x, b.y, b.z, b.w, c.z, c.w, bound, tb);
+                child_a = ch.x;
+                child_b = ch.y;
+                nb += 2;
+            } else if (lane < take) {
+                const float4 *tp = wide_tri<BIG>(s, e);
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                hit = intersect_triangle_watertight(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                                                    q2.x, bound, h0, h1, h2, ht);
+                hp = __float_as_int(q2.y);
+                nt += 1;
+            }
+            // the round's hits, one after the other, into (t1, p1) and (t2, p2): the two nearest
+            // distinct triangles (a triangle met again through another of its leaves is no second)
+            unsigned long long hm = __ballot(hit);
+            while (hm) {
+                const int src = __ffsll((long long)hm) - 1;
+                hm &= hm - 1ull;
+                const float tt = __shfl(ht, src, 64);
+                const int32_t pp = __shfl(hp, src, 64);
+                if (!(tt == tt)) {
+                    tie = true;
+                } else if (pp == p1) {
+                } else if (p1 < 0 || tt < t1) {
+                    if (p1 >= 0) { t2 = t1; p2 = p1; }
+                    t1 = tt; p1 = pp;
+                    c0 = __shfl(h0, src, 64); c1 = __shfl(h1, src, 64); c2 = __shfl(h2, src, 64);
+                } else if (pp != p2 && tt < t2) {
+                    t2 = tt; p2 = pp;
+                } else if (pp == p2) {
+                    t2 = fminf(t2, tt);
+                }
+            }
+            if (p1 >= 0) {
+                bound = t1 + t1 * PT_TIE_WINDOW;
+                tie |= bound >= tmax;
+            }
+            const unsigned long long ma = __ballot(push_a), mb = __ballot(push_b);
+            const int na = (int)__popcll(ma), n_push = na + (int)__popcll(mb);
+            if (top + n_push > kLongStack) {
+                overflow = true;
+                break;
+            }
+            if (push_a) stk[top + (int)__popcll(ma & below)] = child_a;
+            if (push_b) stk[top + na + (int)__popcll(mb & below)] = child_b;
+            top += n_push;
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+        }
+        exact = overflow || tie || (p1 >= 0 && t2 <= t1 + t1 * PT_TIE_WINDOW);
+        primid = p1;
+        shapeid = p1 >= 0 ? 0 : -1;
+        b0 = c0; b1 = c1; b2 = c2;
+        t = p1 >= 0 ? t1 : tmax;
+        if (exact && lane == 0) atomicAdd(tie_count, 1u);
+        exact = exact && fixup;
+    }
+    if (exact) {
+        unsigned long long xb = 0, xt = 0;
+        traverse_skiplink<false, false>(s, ro, rd, shapeid, primid, b0, b1, b2, t, xb, xt);
+    }
+    if (lane == 0) sink(ray, shapeid, primid, b0, b1, b2, t);
+    if (work) {
+        nb = wave_sum(nb);
+        nt = wave_sum(nt);
+        if (lane == 0) {
+            atomicAdd(&work->box_tests, nb);
+            atomicAdd(&work->tri_tests, nt);
         }
     }
 }

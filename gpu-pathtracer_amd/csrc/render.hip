@@ -403,6 +403,7 @@ void launch_pt_extend(hipStream_t st, const DeviceScene &s, const RenderWorkspac
         const K k = (quad ? quad_table : table)[(work ? 4 : 0) | (pp.cache_nodes > 0 ? 2 : 0) | (s.big ? 1 : 0)];
         launch_persistent(k, st, blocks(max_rays, kBlock), cfg, pp, s, (const pt_ray *)ws.rays[buf], ws.hits, count,
                           tie_count, work, pp);
+        launch_long_rays(st, s, (const pt_ray *)ws.rays[buf], ws.hits, true, pp, tie_count, work);
         return;
     }
     if (work)

@@ -167,6 +167,32 @@ __global__ __launch_bounds__(kBlock, PT_EXTEND_MIN_WAVES) void k_trace_any_two_l
                                                                               nullptr, OccludedSink{occluded});
 }
 
+// The rays the persistent closest-hit kernel handed over, one wave each (long_ray_search).  The
+// last wave to finish empties the list for the next launch: by then every wave has read the count.
+template <bool BIG>
+__global__ __launch_bounds__(256) void k_trace_long_rays(DeviceScene s, const pt_ray *rays, pt_hit *hits,
+                                                         bool fixup, PersistentParams pp,
+                                                         unsigned int *tie_count,
+                                                         DeviceTraceCounters *work) {
+    __shared__ int32_t s_stk[4][kLongStack];
+    uint32_t *const list = pp.long_list;
+    const uint32_t listed = list[0];
+    const uint32_t count = listed < pp.long_cap ? listed : pp.long_cap;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    for (uint32_t i = wave; i < count; i += n_waves)
+        long_ray_search<BIG>(s, rays, list[kLongListHeader + i], s_stk[threadIdx.x >> 6], fixup, tie_count,
+                             work, HitSink{hits});
+    if ((threadIdx.x & 63u) == 0u) {
+        __threadfence();
+        if (atomicAdd(&list[1], 1u) == n_waves - 1u) {
+            if (work && count) atomicAdd(&work->long_rays, count);
+            list[0] = 0u;
+            list[1] = 0u;
+            __threadfence();
+        }
+    }
+}
+
 // Sort key of a ray: 30-bit Morton code of its origin's cell in a 1024^3 grid over the scene's
 // root box.  Rays that start close together walk the same part of the tree; on scenes much
 // larger than the caches that is worth more than the sort costs.
@@ -312,7 +338,7 @@ __global__ __launch_bounds__(256) void k_build_quad(const float4 *wnodes, uint32
         }
         org[a] = mn;
         float sc = (mx - mn) / 255.0f;
-        ok &= (fabsf(mn) < INFINITY) & (fabsf(mx) < INFINITY) & (sc == sc) & (sc < INFINITY);
+        ok = ok && fabsf(mn) < INFINITY && fabsf(mx) < INFINITY && sc == sc && sc < INFINITY;
         if (ok)
             for (int guard = 0; guard < 64 && __builtin_fmaf(255.0f, sc, mn) < mx; ++guard)
                 sc = __uint_as_float(__float_as_uint(sc) + 1u);        // next float up (sc >= 0)
@@ -492,6 +518,18 @@ unsigned int persistent_grid(const void *kernel, int block, const ExtendConfig &
     return cfg.max_grid ? std::min(grid, cfg.max_grid) : grid;
 }
 
+void launch_long_rays(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits, bool fixup,
+                      const PersistentParams &pp, unsigned int *tie_count, DeviceTraceCounters *work) {
+    if (!pp.long_list || pp.tail_budget <= 0 || s.tlas) return;
+    constexpr unsigned int kLongGrid = 64;               // 256 waves: the lists are short
+    if (s.big)
+        hipLaunchKernelGGL(k_trace_long_rays<true>, dim3(kLongGrid), dim3(256), 0, st, s, rays, hits, fixup, pp,
+                           tie_count, work);
+    else
+        hipLaunchKernelGGL(k_trace_long_rays<false>, dim3(kLongGrid), dim3(256), 0, st, s, rays, hits, fixup, pp,
+                           tie_count, work);
+}
+
 void launch_trace_skiplink(hipStream_t st, const DeviceScene &s, const pt_ray *rays, pt_hit *hits,
                            uint64_t n, bool moller_trumbore, DeviceTraceCounters *counters) {
     if (n == 0) return;
@@ -598,6 +636,7 @@ void launch_trace_ordered(hipStream_t st, const DeviceScene &s, const pt_ray *ra
         const K k = (quad ? quad_table : table)[(count_work ? 4 : 0) | (cached ? 2 : 0) | (s.big ? 1 : 0)];
         if (bracket) (void)hipEventRecord(bracket[0], st);
         launch_persistent(k, st, grid_for(n), cfg, pp, s, rays, hits, (uint32_t)n, fixup, pp, counters, perm);
+        launch_long_rays(st, s, rays, hits, fixup, pp, &counters->tie_count, counters);
         if (bracket) (void)hipEventRecord(bracket[1], st);
         return;
     }
@@ -692,6 +731,7 @@ int launch_trace_static(hipStream_t st, int device, const DeviceScene &s, const 
     cfg.spill_entries = kStaticSpillEntries;
     cfg.max_grid = kStaticMaxGrid;
     cfg.sort_rays = 0;                  // a sorted call needs room in proportion to n
+    cfg.long_list = nullptr;            // one kernel: every wave finishes its own rays
     const bool exact = (flags & (PT_TRACE_EXACT_ORDER | PT_TRACE_MOLLER_TRUMBORE)) != 0;
     const bool fixup = (flags & PT_TRACE_NO_TIE_FIXUP) == 0;
     if (s.tlas)

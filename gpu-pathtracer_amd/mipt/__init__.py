@@ -71,7 +71,7 @@ class RenderParams(C.Structure):
 
 class TraceStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("tie_rays", C.c_uint64), ("lds_box_tests", C.c_uint64)]
+                ("tie_rays", C.c_uint64), ("lds_box_tests", C.c_uint64), ("long_rays", C.c_uint64)]
 
 
 class RenderStats(C.Structure):

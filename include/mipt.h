@@ -87,6 +87,7 @@ typedef struct pt_trace_stats {
     uint64_t tri_tests;         /* ray/triangle tests */
     uint64_t tie_rays;          /* rays re-resolved in skip-link order */
     uint64_t lds_box_tests;     /* of box_tests: on nodes served from the LDS copy of the top of the tree */
+    uint64_t long_rays;         /* rays finished by a whole wave each (see "extend.tail_budget") */
 } pt_trace_stats;
 
 /* Counters of one pt_render call. */
@@ -223,6 +224,13 @@ int pt_context_last_trace_ms(pt_context *ctx, double *ms);
  * trace calls on scenes beyond the Infinity Cache, render passes on such scenes from the
  * second bounce on); "scene.quad" 1|0: scenes created from now
  * on get that form built (64 bytes per node and per triangle; default 1);
+ * "extend.tail_budget" 0..1000000 (default 64): closest hits on single-level scenes walked as
+ * four-child nodes (see "extend.quad") -- once a
+ * wave of the persistent kernel has no more rays to start, it may spend this many more rounds
+ * (a run of node steps and a triangle step) on the rays it still holds; what is left then (a
+ * ray along a fan of slivers can make thousands of steps) goes to a second kernel that searches
+ * each such ray with a whole wave, so that one ray does not hold the launch (0: every wave
+ * finishes its own rays);
  * "any.exact_order" 0|1: occlusion queries walk the reference's skip links
  * instead of the two-child nodes (default 0); "trace.sort_rays" -1|0|1: pt_trace_closest*
  * takes the rays in Morton order of their origins (default -1: when the scene exceeds the

@@ -42,6 +42,26 @@ def _check_all_modes(mipt, oracle, ctx, nodes, vtx, idx, rays, expect_ties=None,
         bad = same_hits(quad, want, nan_equal)
         assert len(bad) == 0, (f"four-child traversal differs from the oracle on {len(bad)} of "
                                f"{len(rays)} rays, first {bad[:8]}: {quad[bad[:3]]} vs {want[bad[:3]]}")
+        # the same again with the waves' last rays handed to the wave-per-ray search after one
+        # round instead of 64 (what a launch does with rays that would hold it up): the rays that
+        # went that way are counted, and every record is the same
+        ctx.set_option("extend.tail_budget", 1)
+        try:
+            for q in (0, 1):
+                ctx.set_option("extend.quad", q)
+                handed, sth = sc.trace_closest(rays, mipt.PT_TRACE_DEFAULT, stats=True)
+                bad = same_hits(handed, want, nan_equal)
+                assert len(bad) == 0, (f"with rays handed to the wave-per-ray search ({sth.long_rays} of them, "
+                                       f"{'four' if q else 'two'}-child walk) {len(bad)} of {len(rays)} rays "
+                                       f"differ from the oracle, first {bad[:8]}: {handed[bad[:3]]} vs {want[bad[:3]]}")
+                # (the hand-over is part of the four-child kernels only)
+                if q == 0:
+                    assert sth.long_rays == 0
+                elif len(rays) >= 4096 and idx.shape[0] >= 1000:
+                    assert sth.long_rays > 0
+        finally:
+            ctx.set_option("extend.tail_budget", 64)
+            ctx.set_option("extend.quad", -1)
         # occlusion queries (IntersectSceneAny) on the same rays, their reach set around the
         # nearest hit so that some are blocked and some are not: two-child and four-child walk
         ra = rays.copy()
@@ -380,12 +400,16 @@ def test_stack_goes_on_in_global_memory(mipt, oracle, gpu_ctx, n):
     # which the last round checks too (any number of re-resolved rays, same hits).
     for entries in (30, 12, 9, -1):          # 9: the smallest the option takes (a four-child walk gets 12)
         gpu_ctx.set_option("extend.stack_entries", entries)
+        # every wave finishes its own rays here (this launch is all tail: one chunk per wave; with
+        # the default budget the deep rays would go to the wave-per-ray search, whose stack holds them)
+        gpu_ctx.set_option("extend.tail_budget", 0)
         try:
             limit = entries - 1 + 48
             expect = None if entries < 0 else ((lambda t: t == 0) if n - 1 <= limit else (lambda t: t > 0))
             got, st = _check_all_modes(mipt, oracle, gpu_ctx, nodes, vtx, idx, rays, expect_ties=expect)
         finally:
             gpu_ctx.set_option("extend.stack_entries", -1)
+            gpu_ctx.set_option("extend.tail_budget", 64)
     assert (got["primid"] >= 0).mean() > 0.3 and (got["primid"] < 0).mean() > 0.05
     sc = mipt.Scene(gpu_ctx, nodes, vtx, idx)
     try:
